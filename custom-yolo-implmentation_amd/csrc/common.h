@@ -1,0 +1,65 @@
+// Shared device/host helpers for the gfx950 kernels of libyolo_hip.so.
+// Layout convention for every activation tensor: NHWC, element type T in {f32, bf16, f16},
+// pixel p = (n*H + h)*W + w, element (p, c) at base[p*ld + c] with ld >= C (ld lets a tensor be a
+// channel slice of a wider concat buffer).  Parameters and statistics are fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define YOLO_F32 0
+#define YOLO_BF16 1
+#define YOLO_F16 2
+
+#define YOLO_OK 0
+#define YOLO_ERR_ARG 1001      // unsupported argument combination
+#define YOLO_ERR_DTYPE 1002
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+template <typename T> struct vec_of;           // widest 16-byte vector of T
+template <> struct vec_of<float>  { static constexpr int N = 4; };
+template <> struct vec_of<bf16_t> { static constexpr int N = 8; };
+template <> struct vec_of<f16_t>  { static constexpr int N = 8; };
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
+
+// 16-byte (or narrower) packet of V elements of T
+template <typename T, int V> struct alignas(sizeof(T) * V) pack_t { T v[V]; };
+
+template <typename T, int V>
+__device__ __forceinline__ void load_pack(const T* p, float (&out)[V]) {
+    pack_t<T, V> t = *reinterpret_cast<const pack_t<T, V>*>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = to_f<T>(t.v[i]);
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_pack(T* p, const float (&in)[V]) {
+    pack_t<T, V> t;
+#pragma unroll
+    for (int i = 0; i < V; ++i) t.v[i] = from_f<T>(in[i]);
+    *reinterpret_cast<pack_t<T, V>*>(p) = t;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int hip_status(hipError_t e) { return e == hipSuccess ? YOLO_OK : (int)e; }
+#define YOLO_LAUNCH_CHECK() hip_status(hipGetLastError())
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// dispatch on the activation dtype code
+#define YOLO_DISPATCH_T(dtype, ...)                                   \
+    switch (dtype) {                                                  \
+        case YOLO_F32:  { using T = float;  __VA_ARGS__; } break;     \
+        case YOLO_BF16: { using T = bf16_t; __VA_ARGS__; } break;     \
+        case YOLO_F16:  { using T = f16_t;  __VA_ARGS__; } break;     \
+        default: return YOLO_ERR_DTYPE;                               \
+    }

@@ -1,0 +1,432 @@
+// Dtype-generic (f32 / bf16 / f16, fp32 accumulate) convolution kernels: the correctness anchor and
+// the path for shapes the MFMA kernels do not take (fp32, stem Cin=3, odd channel counts), plus
+// depthwise 3x3, weight packing and the host-side launch logic shared with conv_mfma.hip.
+#include "common.h"
+#include "conv_geom.h"
+
+// implemented in conv_mfma.hip
+int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst);
+int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst,
+                     int accumulate, int dtype, hipStream_t st);
+int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const void* x, const void* dy);
+int mfma_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W,
+                      int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// generic gather conv: one thread per (dst pixel, cd), cd fastest
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V, bool ACC>
+__global__ void k_conv_generic(ConvGeom g, const T* __restrict__ src, const T* __restrict__ wm,
+                               const float* __restrict__ bias, T* __restrict__ dst) {
+    long total = (long)g.N * g.Hg * g.Wg * g.Cd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cd = (int)(i % g.Cd);
+        long q = i / g.Cd;
+        int b = (int)(q % g.Wg);
+        long t2 = q / g.Wg;
+        int a = (int)(t2 % g.Hg);
+        long n = t2 / g.Hg;
+        float acc = bias ? bias[cd] : 0.f;
+        const T* wrow = wm + (long)cd * g.Kpad;
+        for (int t = 0; t < g.ntaps; ++t) {
+            int hs = a * g.sstride + g.dh[t], ws = b * g.sstride + g.dw[t];
+            if (hs < 0 || hs >= g.Hs || ws < 0 || ws >= g.Ws) continue;
+            const T* sp = src + ((n * g.Hs + hs) * g.Ws + ws) * (long)g.lds;
+            const T* wp = wrow + t * g.Cs;
+            for (int c = 0; c < g.Cs; c += V) {
+                float xs[V], wv[V];
+                load_pack<T, V>(sp + c, xs);
+                load_pack<T, V>(wp + c, wv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc = fmaf(xs[j], wv[j], acc);
+            }
+        }
+        long dp = ((n * g.Hd + a * g.ostep + g.ooff_h) * g.Wd + b * g.ostep + g.ooff_w) * (long)g.ldd + cd;
+        if (ACC) acc += to_f<T>(dst[dp]);
+        dst[dp] = from_f<T>(acc);
+    }
+}
+
+// dst pixels of an odd-sized map that no parity class covers do not exist; but classes with zero
+// taps never occur (every class has >= 1 tap), so every dx element is written exactly once.
+
+// ------------------------------------------------------------------------------------------------
+// generic wgrad: dwp[co][t*Cin+ci] += sum_p dy[p][co] * x[p (+) t][ci]; slabs of output rows, atomics
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_wgrad_generic(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int ldy,
+                                float* __restrict__ dwp, int Kpad, int N, int H, int W, int Cin, int OH, int OW,
+                                int Cout, int k, int stride, int rows_per_slab) {
+    const int K = k * k * Cin;
+    long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= (long)Cout * K) return;
+    int co = (int)(e / K);
+    int kk = (int)(e - (long)co * K);
+    int t = kk / Cin, ci = kk - t * Cin;
+    int kh = t / k, kw = t - kh * k, pad = k / 2;
+    long r0 = (long)blockIdx.y * rows_per_slab, r1 = r0 + rows_per_slab;
+    long nrows = (long)N * OH;
+    if (r1 > nrows) r1 = nrows;
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        long n = r / OH;
+        int oh = (int)(r - n * OH);
+        int ih = oh * stride + kh - pad;
+        if (ih < 0 || ih >= H) continue;
+        const T* dyr = dy + (r * OW) * (long)ldy + co;
+        const T* xr = x + ((n * H + ih) * W) * (long)ldx + ci;
+        for (int ow = 0; ow < OW; ++ow) {
+            int iw = ow * stride + kw - pad;
+            if (iw < 0 || iw >= W) continue;
+            acc = fmaf(to_f<T>(dyr[(long)ow * ldy]), to_f<T>(xr[(long)iw * ldx]), acc);
+        }
+    }
+    atomicAdd(dwp + (long)co * Kpad + kk, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing.  Source: OIHW parameter (dtype P).  Destination rows of Kpad elements of T.
+//   fwd  : out[o][t*I + i] = w[o][i][kh_t][kw_t]
+//   dgrad: out[i][t*O + o] = w[o][i][kh_t][kw_t]     (kh_t, kw_t from conv_taps)
+// ------------------------------------------------------------------------------------------------
+struct TapIdx { int n; int kh[9], kw[9]; };
+
+template <typename P, typename T>
+__global__ void k_pack_weights(const P* __restrict__ w, int O, int I, int k, int mode, TapIdx taps,
+                               T* __restrict__ out, int Kpad) {
+    const int rows = mode == 0 ? O : I;
+    const int inner = mode == 0 ? I : O;
+    long total = (long)rows * Kpad;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int r = (int)(e / Kpad);
+        int kk = (int)(e - (long)r * Kpad);
+        float v = 0.f;
+        if (kk < taps.n * inner) {
+            int t = kk / inner, c = kk - t * inner;
+            int o = mode == 0 ? r : c, i = mode == 0 ? c : r;
+            v = to_f<P>(w[(((long)o * I + i) * k + taps.kh[t]) * k + taps.kw[t]]);
+        }
+        out[e] = from_f<T>(v);
+    }
+}
+
+// dw (OIHW, dtype P) = dwp[o][(kh*k+kw)*I + i]
+template <typename P>
+__global__ void k_unpack_wgrad(const float* __restrict__ dwp, int O, int I, int k, int Kpad, P* __restrict__ dw) {
+    long total = (long)O * I * k * k;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int kw = (int)(e % k);
+        long r = e / k;
+        int kh = (int)(r % k);
+        r /= k;
+        int i = (int)(r % I);
+        int o = (int)(r / I);
+        dw[e] = from_f<P>(dwp[(long)o * Kpad + (kh * k + kw) * I + i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 3x3 stride 1 pad 1.  Weights: fp32 [C][9] (the OIHW parameter (C,1,3,3) viewed flat,
+// cast by the caller).  FLIP selects the data-gradient form.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V, bool FLIP>
+__global__ void k_dw3x3(const T* __restrict__ x, int ldx, const float* __restrict__ w, T* __restrict__ y, int ldy,
+                        int N, int H, int W, int C) {
+    const int cv = C / V;
+    long total = (long)N * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        int ww = (int)(p % W);
+        long t = p / W;
+        int hh = (int)(t % H);
+        long n = t / H;
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            int hs = hh + kh - 1;
+            if (hs < 0 || hs >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int ws = ww + kw - 1;
+                if (ws < 0 || ws >= W) continue;
+                float a[V];
+                load_pack<T, V>(x + ((n * H + hs) * W + ws) * (long)ldx + cg * V, a);
+                int tap = FLIP ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw;
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], w[(cg * V + j) * 9 + tap], acc[j]);
+            }
+        }
+        store_pack<T, V>(y + p * (long)ldy + cg * V, acc);
+    }
+}
+
+// dw[c][tap] += sum_p dy[p][c] * x[p (+) tap][c]; block = 64 channels x 4 row-lanes, slab of rows
+template <typename T>
+__global__ void k_dw3x3_wgrad(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int ldy,
+                              float* __restrict__ dw, int N, int H, int W, int C, int rows_per_slab) {
+    __shared__ float red[4][64][9];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    long r0 = (long)blockIdx.y * rows_per_slab, r1 = r0 + rows_per_slab, nrows = (long)N * H;
+    if (r1 > nrows) r1 = nrows;
+    if (c < C) {
+        for (long r = r0 + rl; r < r1; r += 4) {
+            long n = r / H;
+            int hh = (int)(r - n * H);
+            for (int ww = 0; ww < W; ++ww) {
+                float g = to_f<T>(dy[(r * W + ww) * (long)ldy + c]);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    int hs = hh + kh - 1;
+                    if (hs < 0 || hs >= H) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        int ws = ww + kw - 1;
+                        if (ws < 0 || ws >= W) continue;
+                        acc[kh * 3 + kw] = fmaf(g, to_f<T>(x[((n * H + hs) * W + ws) * (long)ldx + c]), acc[kh * 3 + kw]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[rl][cl][t] = acc[t];
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            atomicAdd(dw + (long)c * 9 + t, red[0][cl][t] + red[1][cl][t] + red[2][cl][t] + red[3][cl][t]);
+    }
+}
+
+template <typename T> __host__ bool vecok(const void* p, long ld, int C) {
+    constexpr int V = vec_of<T>::N;
+    return (C % V == 0) && (ld % V == 0) && ((reinterpret_cast<uintptr_t>(p) % 16) == 0);
+}
+
+int grid_for(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+int launch_generic(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+                   int dtype, hipStream_t st) {
+    long total = (long)g.N * g.Hg * g.Wg * g.Cd;
+    if (total == 0) return YOLO_OK;
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vecok<T>(src, g.lds, g.Cs) && vecok<T>(wm, g.Kpad, g.Cs);
+        if (ok) {
+            constexpr int V = vec_of<T>::N;
+            if (accumulate) hipLaunchKernelGGL((k_conv_generic<T, V, true>), dim3(grid_for(total)), dim3(256), 0, st, g,
+                                               (const T*)src, (const T*)wm, bias, (T*)dst);
+            else hipLaunchKernelGGL((k_conv_generic<T, V, false>), dim3(grid_for(total)), dim3(256), 0, st, g,
+                                    (const T*)src, (const T*)wm, bias, (T*)dst);
+        } else {
+            if (accumulate) hipLaunchKernelGGL((k_conv_generic<T, 1, true>), dim3(grid_for(total)), dim3(256), 0, st, g,
+                                               (const T*)src, (const T*)wm, bias, (T*)dst);
+            else hipLaunchKernelGGL((k_conv_generic<T, 1, false>), dim3(grid_for(total)), dim3(256), 0, st, g,
+                                    (const T*)src, (const T*)wm, bias, (T*)dst);
+        }
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int run_conv(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+             int dtype, int algo, hipStream_t st) {
+    if (algo != 1 && mfma_conv_eligible(g, dtype, src, wm, dst))
+        return mfma_conv_launch(g, src, wm, bias, dst, accumulate, dtype, st);
+    if (algo == 2) return YOLO_ERR_ARG;   // MFMA demanded but the shape is not eligible
+    return launch_generic(g, src, wm, bias, dst, accumulate, dtype, st);
+}
+
+bool supported(int k, int stride) { return (k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)); }
+
+}  // namespace
+
+extern "C" {
+
+// Elements per packed row: K = ntaps * inner rounded up to 32 (zero padded), so MFMA K-steps never
+// read past a row.
+int yolo_conv_kpad(int O, int I, int k, int stride, int mode, int cls) {
+    int dh[9], dw[9], kh[9], kw[9];
+    int nt = conv_taps(mode, k, stride, cls, dh, dw, kh, kw);
+    return round_up32(nt * (mode == 0 ? I : O));
+}
+
+// total elements of the dgrad weight buffer (1 matrix for stride 1, 4 class matrices for stride 2)
+long yolo_conv_dgrad_wbuf_elems(int O, int I, int k, int stride) {
+    if (stride == 1) return (long)I * yolo_conv_kpad(O, I, k, 1, 1, 0);
+    long s = 0;
+    for (int c = 0; c < 4; ++c) s += (long)I * yolo_conv_kpad(O, I, k, 2, 1, c);
+    return s;
+}
+
+// mode 0: forward matrix [O][Kpad].  mode 1: dgrad buffer (all classes, back to back).
+int yolo_conv_pack_weights(const void* w_oihw, int w_dtype, int O, int I, int k, int stride, int mode, void* out,
+                           int out_dtype, hipStream_t st) {
+    if (!supported(k, stride)) return YOLO_ERR_ARG;
+    int ncls = (mode == 1 && stride == 2) ? 4 : 1;
+    long off = 0;
+    for (int c = 0; c < ncls; ++c) {
+        TapIdx taps;
+        int dh[9], dw[9];
+        taps.n = conv_taps(mode, k, stride, c, dh, dw, taps.kh, taps.kw);
+        int Kpad = round_up32(taps.n * (mode == 0 ? I : O));
+        long total = (long)(mode == 0 ? O : I) * Kpad;
+#define PACK_LAUNCH(P)                                                                                               \
+    YOLO_DISPATCH_T(out_dtype, hipLaunchKernelGGL((k_pack_weights<P, T>), dim3(grid_for(total)), dim3(256), 0, st,   \
+                                                  (const P*)w_oihw, O, I, k, mode, taps, (T*)out + off, Kpad))
+        switch (w_dtype) {
+            case YOLO_F32:  PACK_LAUNCH(float); break;
+            case YOLO_BF16: PACK_LAUNCH(bf16_t); break;
+            case YOLO_F16:  PACK_LAUNCH(f16_t); break;
+            default: return YOLO_ERR_DTYPE;
+        }
+#undef PACK_LAUNCH
+        off += total;
+    }
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_conv_unpack_wgrad(const float* dwp, int O, int I, int k, void* dw_oihw, int dw_dtype, hipStream_t st) {
+    int Kpad = round_up32(k * k * I);
+    long total = (long)O * I * k * k;
+    switch (dw_dtype) {
+        case YOLO_F32:  hipLaunchKernelGGL((k_unpack_wgrad<float>), dim3(grid_for(total)), dim3(256), 0, st, dwp, O, I, k, Kpad, (float*)dw_oihw); break;
+        case YOLO_BF16: hipLaunchKernelGGL((k_unpack_wgrad<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, dwp, O, I, k, Kpad, (bf16_t*)dw_oihw); break;
+        case YOLO_F16:  hipLaunchKernelGGL((k_unpack_wgrad<f16_t>), dim3(grid_for(total)), dim3(256), 0, st, dwp, O, I, k, Kpad, (f16_t*)dw_oihw); break;
+        default: return YOLO_ERR_DTYPE;
+    }
+    return YOLO_LAUNCH_CHECK();
+}
+
+// y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], w) (+ bias); pad = k/2; wp = forward-packed weights in `dtype`.
+// algo: 0 auto (MFMA when eligible), 1 generic VALU kernel, 2 MFMA or error.
+int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, int N, int H, int W,
+                    int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st) {
+    if (!supported(k, stride)) return YOLO_ERR_ARG;
+    int pad = k / 2;
+    if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return YOLO_ERR_ARG;
+    ConvGeom g;
+    g.N = N; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lds = ldx;
+    g.Hd = OH; g.Wd = OW; g.Cd = Cout; g.ldd = ldy; g.Hg = OH; g.Wg = OW;
+    g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = stride;
+    int kh[9], kw[9];
+    g.ntaps = conv_taps(0, k, stride, 0, g.dh, g.dw, kh, kw);
+    g.K = g.ntaps * Cin; g.Kpad = round_up32(g.K);
+    return run_conv(g, x, wp, bias, y, 0, dtype, algo, st);
+}
+
+// dx[N,H,W,Cin] (= or +=) conv^T(dy[N,OH,OW,Cout]); wb = dgrad-packed buffer from yolo_conv_pack_weights(mode 1)
+int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin,
+                      int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo,
+                      hipStream_t st) {
+    if (!supported(k, stride)) return YOLO_ERR_ARG;
+    size_t esz = dtype == YOLO_F32 ? 4 : 2;
+    int ncls = stride == 2 ? 4 : 1;
+    long off = 0;
+    for (int c = 0; c < ncls; ++c) {
+        ConvGeom g;
+        g.N = N; g.Hs = OH; g.Ws = OW; g.Cs = Cout; g.lds = lddy;
+        g.Hd = H; g.Wd = W; g.Cd = Cin; g.ldd = lddx;
+        int kh[9], kw[9];
+        g.ntaps = conv_taps(1, k, stride, c, g.dh, g.dw, kh, kw);
+        g.K = g.ntaps * Cout; g.Kpad = round_up32(g.K);
+        if (stride == 1) {
+            g.Hg = H; g.Wg = W; g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = 1;
+        } else {
+            int ph = c >> 1, pw = c & 1;
+            g.Hg = ph == 0 ? (H + 1) / 2 : H / 2;
+            g.Wg = pw == 0 ? (W + 1) / 2 : W / 2;
+            g.ostep = 2; g.ooff_h = ph; g.ooff_w = pw; g.sstride = 1;
+        }
+        if (g.Hg > 0 && g.Wg > 0) {
+            int rc = run_conv(g, dy, (const char*)wb + off * esz, nullptr, dx, accumulate, dtype, algo, st);
+            if (rc) return rc;
+        }
+        off += (long)Cin * g.Kpad;
+    }
+    return YOLO_OK;
+}
+
+// dwp[Cout][Kpad] fp32 (forward-packed order) = sum over pixels; caller unpacks with yolo_conv_unpack_wgrad.
+// The buffer is zeroed here (the kernels accumulate with atomics over pixel slabs).
+int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dwp, int N, int H, int W, int Cin,
+                      int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st) {
+    if (!supported(k, stride)) return YOLO_ERR_ARG;
+    int K = k * k * Cin, Kpad = round_up32(K);
+    int rc = hip_status(hipMemsetAsync(dwp, 0, (size_t)Cout * Kpad * sizeof(float), st));
+    if (rc) return rc;
+    if (algo != 1 && mfma_wgrad_eligible(Cin, Cout, ldx, ldy, dtype, x, dy))
+        return mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+    if (algo == 2) return YOLO_ERR_ARG;
+    long nrows = (long)N * OH;
+    long elems = (long)Cout * K;
+    int gx = (int)((elems + 255) / 256);
+    long want_slabs = 4096 / (gx > 0 ? gx : 1);
+    if (want_slabs < 1) want_slabs = 1;
+    if (want_slabs > nrows) want_slabs = nrows;
+    int rps = (int)((nrows + want_slabs - 1) / want_slabs);
+    int gy = (int)((nrows + rps - 1) / rps);
+    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_wgrad_generic<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, ldx,
+                                              (const T*)dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, rps));
+    return YOLO_LAUNCH_CHECK();
+}
+
+// depthwise 3x3 stride 1 pad 1; w = fp32 [C][9]
+int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
+                       hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        if (vecok<T>(x, ldx, C) && vecok<T>(y, ldy, C)) {
+            constexpr int V = vec_of<T>::N;
+            hipLaunchKernelGGL((k_dw3x3<T, V, false>), dim3(grid_for((long)N * H * W * (C / V))), dim3(256), 0, st,
+                               (const T*)x, ldx, w, (T*)y, ldy, N, H, W, C);
+        } else {
+            hipLaunchKernelGGL((k_dw3x3<T, 1, false>), dim3(grid_for((long)N * H * W * C)), dim3(256), 0, st, (const T*)x,
+                               ldx, w, (T*)y, ldy, N, H, W, C);
+        }
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C,
+                         int dtype, hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        if (vecok<T>(dy, lddy, C) && vecok<T>(dx, lddx, C)) {
+            constexpr int V = vec_of<T>::N;
+            hipLaunchKernelGGL((k_dw3x3<T, V, true>), dim3(grid_for((long)N * H * W * (C / V))), dim3(256), 0, st,
+                               (const T*)dy, lddy, w, (T*)dx, lddx, N, H, W, C);
+        } else {
+            hipLaunchKernelGGL((k_dw3x3<T, 1, true>), dim3(grid_for((long)N * H * W * C)), dim3(256), 0, st, (const T*)dy,
+                               lddy, w, (T*)dx, lddx, N, H, W, C);
+        }
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+// dw fp32 [C][9], zeroed here
+int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, int N, int H, int W, int C,
+                         int dtype, hipStream_t st) {
+    int rc = hip_status(hipMemsetAsync(dw, 0, (size_t)C * 9 * sizeof(float), st));
+    if (rc) return rc;
+    long nrows = (long)N * H;
+    int gx = ceil_div(C, 64);
+    long want = 2048 / gx;
+    if (want < 1) want = 1;
+    if (want > nrows) want = nrows;
+    int rps = (int)((nrows + want - 1) / want);
+    int gy = (int)((nrows + rps - 1) / rps);
+    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw3x3_wgrad<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, ldx,
+                                              (const T*)dy, ldy, dw, N, H, W, C, rps));
+    return YOLO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,372 @@
+// bf16 / f16 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_16x16x32_{bf16,f16}).
+//
+// Forward and data-gradient share one kernel (ConvGeom, conv_geom.h): a 128-pixel x BN-channel
+// output tile per 256-thread workgroup (4 waves), K = taps*Cs walked in 32-element steps.  The
+// activation tile is gathered NHWC row by row (16 B = 8 channels per lane, zero for padding taps),
+// the weight tile comes from the K-major packed matrix; both are staged through LDS (80-byte
+// rows: 64 B payload + 16 B pad to spread ds_read_b128 over the banks) with a register-staged
+// double buffer, one barrier per K-step.  MFMA roles are swapped (A = weights, B = activations) so a
+// lane's four accumulator registers are four CONSECUTIVE output channels of one pixel: the epilogue
+// stores 8 bytes per lane into NHWC rows.
+//
+// Weight-gradient: dW[co][tap][ci] = sum_p dY[p][co] * X[p+tap][ci].  The reduction index is the
+// pixel, which is the slow axis of NHWC, so both tiles are transposed on their way into LDS
+// (pixel-major inner) and the K loop runs over 32-pixel steps of one slab; slabs are combined with
+// fp32 atomics into the packed gradient matrix.
+#include "common.h"
+#include "conv_geom.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <typename T> struct mfma_ops;
+template <> struct mfma_ops<bf16_t> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct mfma_ops<f16_t> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+constexpr int BM = 128;    // destination pixels per workgroup
+constexpr int BK = 32;     // K elements per step (one MFMA K)
+constexpr int LDSROW = 40; // elements per LDS row (32 + 8 pad) = 80 bytes
+
+struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic indexing of kernargs)
+    int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, Hg, Wg, ostep, ooff_h, ooff_w, sstride, ntaps, KT, Kpad;
+    unsigned dh_pack, dw_pack;   // 2 bits per tap: value + 1
+};
+
+// bijective XCD-aware remap (guide T1): blocks that share an XCD get a contiguous range of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename T, int WGM, int WGN, int WM, int WN, bool ACC>
+__global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
+                                                   const float* __restrict__ bias, T* __restrict__ dst, int ntile_n) {
+    static_assert(WGM * WGN == 4 && WGM * WM * 16 == BM, "tile shape");
+    constexpr int BN = WGN * WN * 16;
+    using ops = mfma_ops<T>;
+    using frag = typename ops::frag;
+    __shared__ __attribute__((aligned(16))) T lds_a[2][BM][LDSROW];
+    __shared__ __attribute__((aligned(16))) T lds_b[2][BN][LDSROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = tile / ntile_n, tile_n = tile - tile_m * ntile_n;
+    const long m0 = (long)tile_m * BM;
+    const int cd0 = tile_n * BN;
+    const long total_pix = (long)g.N * g.Hg * g.Wg;
+
+    // ---- loader state: two activation rows (r, r+64) and one weight row per thread, fixed k-segment
+    const int kseg = tid & 3;
+    const int lrow = tid >> 2;                      // 0..63
+    long pbase[2];                                  // ((n*Hs)*Ws) pixel base of the image
+    int hs0[2], ws0[2];
+    bool rvalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        long q = m0 + lrow + i * 64;
+        rvalid[i] = q < total_pix;
+        long qq = rvalid[i] ? q : 0;
+        int b = (int)(qq % g.Wg);
+        long t2 = qq / g.Wg;
+        int a = (int)(t2 % g.Hg);
+        long n = t2 / g.Hg;
+        pbase[i] = n * g.Hs * (long)g.Ws;
+        hs0[i] = a * g.sstride;
+        ws0[i] = b * g.sstride;
+    }
+    constexpr int WR = (BN + 63) / 64;              // weight rows per thread (lrow, lrow+64)
+    bool wvalid[WR];
+    const T* wrow[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        int r = lrow + i * 64;
+        wvalid[i] = (r < BN) && (cd0 + r < g.Cd);
+        wrow[i] = wm + (long)(cd0 + (wvalid[i] ? r : 0)) * g.Kpad + kseg * 8;
+    }
+
+    int tap = 0, ch = kseg * 8;                     // k = tap*Cs + ch for this thread's segment
+    while (ch >= g.Cs) { ch -= g.Cs; ++tap; }
+
+    uint4 ra[2], rb[WR];
+    auto gload = [&](int kt) {
+        int dh = 0, dw = 0;
+        bool tv = tap < g.ntaps;
+        if (tv) {
+            dh = (int)((g.dh_pack >> (2 * tap)) & 3u) - 1;
+            dw = (int)((g.dw_pack >> (2 * tap)) & 3u) - 1;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int hs = hs0[i] + dh, ws = ws0[i] + dw;
+            bool ok = tv && rvalid[i] && hs >= 0 && hs < g.Hs && ws >= 0 && ws < g.Ws;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (ok) ra[i] = *reinterpret_cast<const uint4*>(src + (pbase[i] + (long)hs * g.Ws + ws) * g.lds + ch);
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (wvalid[i]) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (long)kt * BK);
+        }
+        ch += BK;
+        while (ch >= g.Cs) { ch -= g.Cs; ++tap; }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint4*>(&lds_a[buf][lrow + i * 64][kseg * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            if (lrow + i * 64 < BN) *reinterpret_cast<uint4*>(&lds_b[buf][lrow + i * 64][kseg * 8]) = rb[i];
+    };
+
+    // ---- compute state
+    const int wgm = wave / WGN, wgn = wave - wgm * WGN;
+    const int prow = wgm * WM * 16, crow = wgn * WN * 16;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < g.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < g.KT) gload(kt + 1);
+        frag fa[WN], fb[WM];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) fa[j] = *reinterpret_cast<const frag*>(&lds_b[buf][crow + j * 16 + fr][fk]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) fb[i] = *reinterpret_cast<const frag*>(&lds_a[buf][prow + i * 16 + fr][fk]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = ops::mma(fa[j], fb[i], acc[i][j]);
+        if (kt + 1 < g.KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels cbase..cbase+3 of pixel (tile pixel i*16 + fr)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        long q = m0 + prow + i * 16 + fr;
+        if (q >= total_pix) continue;
+        int b = (int)(q % g.Wg);
+        long t2 = q / g.Wg;
+        int a = (int)(t2 % g.Hg);
+        long n = t2 / g.Hg;
+        T* drow = dst + ((n * g.Hd + a * g.ostep + g.ooff_h) * (long)g.Wd + b * g.ostep + g.ooff_w) * g.ldd;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            int cbase = cd0 + crow + j * 16 + (lane >> 4) * 4;
+            if (cbase >= g.Cd) continue;            // Cd % 8 == 0 => a group of 4 is all-in or all-out
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[cbase + r] : 0.f);
+            if (ACC) {
+                float o[4];
+                load_pack<T, 4>(drow + cbase, o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += o[r];
+            }
+            store_pack<T, 4>(drow + cbase, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_BP = 32;   // pixels per K-step
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int ldy,
+                                                    float* __restrict__ dwp, int Kpad, int N, int H, int W, int Cin,
+                                                    int OH, int OW, int Cout, int k, int stride, int ci_tiles,
+                                                    long slab_pix) {
+    using ops = mfma_ops<T>;
+    using frag = typename ops::frag;
+    __shared__ __attribute__((aligned(16))) T lds_y[64][LDSROW];   // [co][pixel]
+    __shared__ __attribute__((aligned(16))) T lds_x[64][LDSROW];   // [ci][pixel]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * 64;
+    const int tapi = blockIdx.y / ci_tiles;
+    const int ci0 = (blockIdx.y - tapi * ci_tiles) * 64;
+    const int kh = tapi / k, kw = tapi - kh * k, pad = k / 2;
+    const long P = (long)N * OH * OW;
+    const long q0 = (long)blockIdx.z * slab_pix;
+    long q1 = q0 + slab_pix;
+    if (q1 > P) q1 = P;
+    const int steps = (int)((q1 - q0 + WG_BP - 1) / WG_BP);
+
+    const int pix = tid & 31, seg = tid >> 5;       // 32 pixels x 8 channel segments
+    const bool yv = co0 + seg * 8 < Cout, xv = ci0 + seg * 8 < Cin;
+
+    uint4 ry, rx;
+    auto gload = [&](int s) {
+        long q = q0 + (long)s * WG_BP + pix;
+        ry = make_uint4(0, 0, 0, 0);
+        rx = make_uint4(0, 0, 0, 0);
+        if (q < q1) {
+            int ow = (int)(q % OW);
+            long t2 = q / OW;
+            int oh = (int)(t2 % OH);
+            long n = t2 / OH;
+            if (yv) ry = *reinterpret_cast<const uint4*>(dy + q * ldy + co0 + seg * 8);
+            int ih = oh * stride + kh - pad, iw = ow * stride + kw - pad;
+            if (xv && ih >= 0 && ih < H && iw >= 0 && iw < W)
+                rx = *reinterpret_cast<const uint4*>(x + ((n * H + ih) * (long)W + iw) * ldx + ci0 + seg * 8);
+        }
+    };
+    auto lstore = [&]() {
+        const T* py = reinterpret_cast<const T*>(&ry);
+        const T* px = reinterpret_cast<const T*>(&rx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            lds_y[seg * 8 + j][pix] = py[j];
+            lds_x[seg * 8 + j][pix] = px[j];
+        }
+    };
+
+    const int wc = wave >> 1, wi = wave & 1;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (steps > 0) gload(0);
+    for (int s = 0; s < steps; ++s) {
+        __syncthreads();            // every wave is done reading the previous step's tiles
+        lstore();
+        __syncthreads();
+        if (s + 1 < steps) gload(s + 1);
+        frag fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const frag*>(&lds_y[wc * 32 + i * 16 + fr][fk]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const frag*>(&lds_x[wi * 32 + j * 16 + fr][fk]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = ops::mma(fa[i], fb[j], acc[i][j]);
+    }
+
+    // D rows = co ((lane>>4)*4 + r), cols = ci (lane & 15)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int ci = ci0 + wi * 32 + j * 16 + fr;
+            if (ci >= Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int co = co0 + wc * 32 + i * 16 + (lane >> 4) * 4 + r;
+                if (co < Cout) atomicAdd(dwp + (long)co * Kpad + tapi * Cin + ci, acc[i][j][r]);
+            }
+        }
+}
+
+GeomDev to_dev(const ConvGeom& g) {
+    GeomDev d;
+    d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd;
+    d.ldd = g.ldd; d.Hg = g.Hg; d.Wg = g.Wg; d.ostep = g.ostep; d.ooff_h = g.ooff_h; d.ooff_w = g.ooff_w;
+    d.sstride = g.sstride; d.ntaps = g.ntaps; d.Kpad = g.Kpad; d.KT = g.Kpad / BK;
+    d.dh_pack = d.dw_pack = 0;
+    for (int t = 0; t < g.ntaps; ++t) {
+        d.dh_pack |= (unsigned)(g.dh[t] + 1) << (2 * t);
+        d.dw_pack |= (unsigned)(g.dw[t] + 1) << (2 * t);
+    }
+    return d;
+}
+
+template <typename T, int WGM, int WGN, int WM, int WN>
+void launch_tile(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+                 hipStream_t st) {
+    constexpr int BN = WGN * WN * 16;
+    long pix = (long)d.N * d.Hg * d.Wg;
+    int tm = (int)((pix + BM - 1) / BM), tn = (d.Cd + BN - 1) / BN;
+    dim3 grid(tm * tn);
+    if (accumulate)
+        hipLaunchKernelGGL((k_conv_mfma<T, WGM, WGN, WM, WN, true>), grid, dim3(256), 0, st, d, (const T*)src,
+                           (const T*)wm, bias, (T*)dst, tn);
+    else
+        hipLaunchKernelGGL((k_conv_mfma<T, WGM, WGN, WM, WN, false>), grid, dim3(256), 0, st, d, (const T*)src,
+                           (const T*)wm, bias, (T*)dst, tn);
+}
+
+template <typename T>
+void launch_conv_t(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+                   hipStream_t st) {
+    if (d.Cd > 64) launch_tile<T, 2, 2, 4, 4>(d, src, wm, bias, dst, accumulate, st);        // 128 x 128
+    else if (d.Cd > 32) launch_tile<T, 2, 2, 4, 2>(d, src, wm, bias, dst, accumulate, st);   // 128 x 64
+    else launch_tile<T, 4, 1, 2, 2>(d, src, wm, bias, dst, accumulate, st);                  // 128 x 32
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst) {
+    if (dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
+    if (g.Cs % 8 || g.lds % 8 || g.Cd % 8 || g.ldd % 4) return 0;
+    if (!al16(src) || !al16(wm) || (reinterpret_cast<uintptr_t>(dst) & 7)) return 0;
+    for (int t = 0; t < g.ntaps; ++t)
+        if (g.dh[t] < -1 || g.dh[t] > 1 || g.dw[t] < -1 || g.dw[t] > 1) return 0;
+    return 1;
+}
+
+int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+                     int dtype, hipStream_t st) {
+    GeomDev d = to_dev(g);
+    if ((long)d.N * d.Hg * d.Wg == 0) return YOLO_OK;
+    if (dtype == YOLO_BF16) launch_conv_t<bf16_t>(d, src, wm, bias, dst, accumulate, st);
+    else launch_conv_t<f16_t>(d, src, wm, bias, dst, accumulate, st);
+    return YOLO_LAUNCH_CHECK();
+}
+
+int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const void* x, const void* dy) {
+    if (dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
+    if (Cin % 8 || Cout % 8 || ldx % 8 || ldy % 8) return 0;
+    return al16(x) && al16(dy);
+}
+
+int mfma_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W,
+                      int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st) {
+    long P = (long)N * OH * OW;
+    if (P == 0) return YOLO_OK;
+    int cot = (Cout + 63) / 64, cit = (Cin + 63) / 64, nt = k * k;
+    long tiles = (long)cot * cit * nt;
+    long max_slabs = 4096 / tiles;
+    if (max_slabs < 1) max_slabs = 1;
+    long slab = (P + max_slabs - 1) / max_slabs;
+    if (slab < 1024) slab = 1024;
+    slab = (slab + WG_BP - 1) / WG_BP * WG_BP;
+    int nslab = (int)((P + slab - 1) / slab);
+    dim3 grid(cot, cit * nt, nslab);
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((k_wgrad_mfma<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, ldy,
+                           dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, cit, slab);
+    else
+        hipLaunchKernelGGL((k_wgrad_mfma<f16_t>), grid, dim3(256), 0, st, (const f16_t*)x, ldx, (const f16_t*)dy, ldy,
+                           dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, cit, slab);
+    return YOLO_LAUNCH_CHECK();
+}

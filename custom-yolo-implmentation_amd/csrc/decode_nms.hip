@@ -1,0 +1,329 @@
+// Inference post-processing: head decode (reference src/model/model_builder.py:123-136) and
+// class-aware NMS (src/utils/model_utils.py:174-279 + torchvision.ops.nms semantics).
+//
+// NMS, per image, all on device, deterministic:
+//   k_candidates : confidence filter + best class (or every class above the threshold when
+//                  multi_label), optional class whitelist, xywh->xyxy with each operation rounded in
+//                  the input dtype T (the reference does this arithmetic in T before torch.cat promotes
+//                  the rows to fp32); order-preserving compaction by block scans
+//   k_rank       : stable descending order by counting (rank = #better), cap 30000 (max_nms)
+//   k_mask       : 64x64 tiles of "IoU(i,j) > thr, j after i" bits on boxes + cls*7680 (class-aware trick
+//                  kept verbatim so the low bits of the fp32 coordinates match the reference)
+//   k_scan       : one wave walks the sorted list, keeps at most max_det
+// fp32 IoU exactly as torchvision: inter / (area_i + area_j - inter), strict >, no eps.
+// Built with -ffp-contract=off: bit-exact index selection needs the un-fused multiply/add order.
+#include "common.h"
+
+namespace {
+
+constexpr int REG = 16;
+constexpr float MAX_WH = 7680.f;
+constexpr int MAX_NMS = 30000;
+
+template <typename T> __device__ __forceinline__ float rt(float v) { return to_f<T>(from_f<T>(v)); }
+
+template <typename T>
+__global__ void k_head_decode(const T* __restrict__ preds, const T* __restrict__ anchors, const T* __restrict__ strides,
+                              T* __restrict__ y, int N, int nc, int A) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)N * A) return;
+    int a = (int)(i % A);
+    long n = i / A;
+    const T* p = preds + n * (long)(4 * REG + nc) * A + a;
+    T* o = y + n * (long)(4 + nc) * A + a;
+    float e[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float x[REG], mx = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < REG; ++b) { x[b] = to_f<T>(p[(long)(s * REG + b) * A]); mx = fmaxf(mx, x[b]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < REG; ++b) { x[b] = expf(x[b] - mx); sum += x[b]; }
+        float ex = 0.f;
+#pragma unroll
+        for (int b = 0; b < REG; ++b) ex += (x[b] / sum) * (float)b;
+        e[s] = ex;
+    }
+    float ax = to_f<T>(anchors[a]), ay = to_f<T>(anchors[A + a]), st = to_f<T>(strides[a]);
+    float x1 = ax - e[0], y1 = ay - e[1], x2 = ax + e[2], y2 = ay + e[3];
+    o[0] = from_f<T>((x1 + x2) / 2.f * st);
+    o[(long)A] = from_f<T>((y1 + y2) / 2.f * st);
+    o[2L * A] = from_f<T>((x2 - x1) * st);
+    o[3L * A] = from_f<T>((y2 - y1) * st);
+    for (int c = 0; c < nc; ++c) o[(long)(4 + c) * A] = p[(long)(4 * REG + c) * A];
+}
+
+// DFL block alone (src/model/model_blocks.py:278-280): (b, 64, a) logits -> (b, 4, a) expected distances
+template <typename T>
+__global__ void k_dfl_expect(const T* __restrict__ x, T* __restrict__ y, int B, int A) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)B * 4 * A) return;
+    int a = (int)(i % A);
+    long t = i / A;
+    int s = (int)(t % 4);
+    long b = t / 4;
+    const T* p = x + (b * 64 + s * REG) * (long)A + a;
+    float v[REG], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < REG; ++k) { v[k] = to_f<T>(p[(long)k * A]); mx = fmaxf(mx, v[k]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < REG; ++k) { v[k] = expf(v[k] - mx); sum += v[k]; }
+    float ex = 0.f;
+#pragma unroll
+    for (int k = 0; k < REG; ++k) ex += (v[k] / sum) * (float)k;
+    y[i] = from_f<T>(ex);
+}
+
+struct ClsFilter { int n; int ids[32]; };
+
+__device__ __forceinline__ bool cls_ok(const ClsFilter& f, int c) {
+    if (f.n == 0) return true;
+    bool ok = false;
+    for (int k = 0; k < f.n; ++k) ok |= (f.ids[k] == c);
+    return ok;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns the block total in `total`
+__device__ __forceinline__ int block_excl_scan(int v, int* lds4, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds4[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += lds4[w];
+    total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    return base + inc - v;
+}
+
+// one workgroup per image
+template <typename T>
+__global__ __launch_bounds__(256) void k_candidates(const T* __restrict__ y, int nc, int M, float conf_thres,
+                                                    int multi_label, ClsFilter filt, int cap,
+                                                    float* __restrict__ rows /*[bs][cap][6]*/,
+                                                    int* __restrict__ count /*[bs]*/, int* __restrict__ overflow) {
+    __shared__ int lds4[4];
+    const int img = blockIdx.x;
+    const T* yi = y + (long)img * (4 + nc) * M;
+    float* out = rows + (long)img * cap * 6;
+    int base = 0;
+    for (int m0 = 0; m0 < M; m0 += 256) {
+        const int m = m0 + threadIdx.x;
+        int cnt = 0, bestc = 0;
+        float best = -INFINITY;
+        if (m < M) {
+            for (int c = 0; c < nc; ++c) {
+                float v = to_f<T>(yi[(long)(4 + c) * M + m]);
+                if (multi_label) { if (v > conf_thres && cls_ok(filt, c)) ++cnt; }
+                else if (v > best) { best = v; bestc = c; }
+            }
+            if (!multi_label) cnt = (best > conf_thres && cls_ok(filt, bestc)) ? 1 : 0;
+        }
+        int total;
+        int pos = base + block_excl_scan(cnt, lds4, total);
+        if (cnt > 0) {
+            float cx = to_f<T>(yi[m]), cy = to_f<T>(yi[(long)M + m]);
+            float dw = rt<T>(to_f<T>(yi[2L * M + m]) / 2.f), dh = rt<T>(to_f<T>(yi[3L * M + m]) / 2.f);
+            float x1 = rt<T>(cx - dw), y1 = rt<T>(cy - dh), x2 = rt<T>(cx + dw), y2 = rt<T>(cy + dh);
+            if (!multi_label) {
+                if (pos < cap) {
+                    float* r = out + (long)pos * 6;
+                    r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = best; r[5] = (float)bestc;
+                }
+            } else {
+                for (int c = 0; c < nc; ++c) {
+                    float v = to_f<T>(yi[(long)(4 + c) * M + m]);
+                    if (v > conf_thres && cls_ok(filt, c)) {
+                        if (pos < cap) {
+                            float* r = out + (long)pos * 6;
+                            r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = v; r[5] = (float)c;
+                        }
+                        ++pos;
+                    }
+                }
+            }
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) {
+        if (base > cap) { *overflow = 1; base = cap; }
+        count[img] = base;
+    }
+}
+
+// rank by counting; order[rank] = i for rank < MAX_NMS.   grid.x covers cap, grid.y = image
+__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ rows, const int* __restrict__ count, int cap,
+                                              int* __restrict__ order /*[bs][MAX_NMS]*/) {
+    __shared__ float sc[256];
+    const int img = blockIdx.y;
+    const int n = count[img];
+    if (blockIdx.x * 256 >= n) return;
+    const float* r = rows + (long)img * cap * 6;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float mine = i < n ? r[(long)i * 6 + 4] : 0.f;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        int j = j0 + threadIdx.x;
+        sc[threadIdx.x] = j < n ? r[(long)j * 6 + 4] : -INFINITY;
+        __syncthreads();
+        int lim = n - j0 < 256 ? n - j0 : 256;
+        for (int k = 0; k < lim; ++k) {
+            float o = sc[k];
+            rank += (o > mine) || (o == mine && j0 + k < i);
+        }
+    }
+    if (i < n && rank < MAX_NMS) order[(long)img * MAX_NMS + rank] = i;
+}
+
+// mask[i][w] bit b: box order[w*64+b] is suppressed by box order[i]  (only j > i)
+__global__ __launch_bounds__(64) void k_mask(const float* __restrict__ rows, const int* __restrict__ count,
+                                             const int* __restrict__ order, int cap, int img, float thr, int agnostic,
+                                             int words, unsigned long long* __restrict__ mask) {
+    __shared__ float bx[64][4];
+    int n = count[img];
+    if (n > MAX_NMS) n = MAX_NMS;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
+    const float* r = rows + (long)img * cap * 6;
+    const int* ord = order + (long)img * MAX_NMS;
+    const int t = threadIdx.x;
+    {
+        int j = bj * 64 + t;
+        if (j < n) {
+            const float* q = r + (long)ord[j] * 6;
+            float off = agnostic ? 0.f : q[5] * MAX_WH;
+            bx[t][0] = q[0] + off; bx[t][1] = q[1] + off; bx[t][2] = q[2] + off; bx[t][3] = q[3] + off;
+        }
+    }
+    __syncthreads();
+    const int i = bi * 64 + t;
+    if (i >= n) return;
+    const float* q = r + (long)ord[i] * 6;
+    const float off = agnostic ? 0.f : q[5] * MAX_WH;
+    const float x1 = q[0] + off, y1 = q[1] + off, x2 = q[2] + off, y2 = q[3] + off;
+    const float area = (x2 - x1) * (y2 - y1);
+    unsigned long long bits = 0ull;
+    const int lim = n - bj * 64 < 64 ? n - bj * 64 : 64;
+    for (int k = 0; k < lim; ++k) {
+        int j = bj * 64 + k;
+        if (j <= i) continue;
+        float w = fmaxf(0.f, fminf(x2, bx[k][2]) - fmaxf(x1, bx[k][0]));
+        float h = fmaxf(0.f, fminf(y2, bx[k][3]) - fmaxf(y1, bx[k][1]));
+        float inter = w * h;
+        float aj = (bx[k][2] - bx[k][0]) * (bx[k][3] - bx[k][1]);
+        float iou = inter / (area + aj - inter);
+        if (iou > thr) bits |= 1ull << k;
+    }
+    mask[(long)i * words + bj] = bits;
+}
+
+__global__ __launch_bounds__(64) void k_scan(const float* __restrict__ rows, const int* __restrict__ count,
+                                             const int* __restrict__ order, int cap, int img, int words, int max_det,
+                                             const unsigned long long* __restrict__ mask,
+                                             float* __restrict__ out /*[bs][max_det][6]*/, int* __restrict__ out_count) {
+    extern __shared__ unsigned long long removed[];
+    int n = count[img];
+    if (n > MAX_NMS) n = MAX_NMS;
+    const int lane = threadIdx.x;
+    const int nw = (n + 63) / 64;
+    for (int w = lane; w < nw; w += 64) removed[w] = 0ull;
+    __syncthreads();
+    const float* r = rows + (long)img * cap * 6;
+    const int* ord = order + (long)img * MAX_NMS;
+    float* o = out + (long)img * max_det * 6;
+    int kept = 0;
+    for (int i = 0; i < n && kept < max_det; ++i) {
+        unsigned long long rw = removed[i >> 6];
+        if ((rw >> (i & 63)) & 1ull) continue;
+        if (lane < 6) o[(long)kept * 6 + lane] = r[(long)ord[i] * 6 + lane];
+        ++kept;
+        __syncthreads();
+        for (int w = (i >> 6) + lane; w < nw; w += 64) removed[w] |= mask[(long)i * words + w];
+        __syncthreads();
+    }
+    if (lane == 0) out_count[img] = kept;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yolo_head_decode(const void* preds, const void* anchors, const void* strides, void* y, int N, int nc, int A,
+                     int dtype, hipStream_t st) {
+    long NA = (long)N * A;
+    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_head_decode<T>), dim3(ceil_div(NA, 256)), dim3(256), 0, st, (const T*)preds,
+                                              (const T*)anchors, (const T*)strides, (T*)y, N, nc, A));
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_dfl_expect(const void* x, void* y, int B, int A, int dtype, hipStream_t st) {
+    long tot = (long)B * 4 * A;
+    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_dfl_expect<T>), dim3(ceil_div(tot, 256)), dim3(256), 0, st, (const T*)x, (T*)y, B, A));
+    return YOLO_LAUNCH_CHECK();
+}
+
+// candidate capacity per image used by yolo_nms and its workspace
+int yolo_nms_capacity(int M, int nc, int multi_label) {
+    long c = (long)M * (multi_label ? nc : 1);
+    return (int)(c > 131072 ? 131072 : c);
+}
+
+size_t yolo_nms_workspace_bytes(int bs, int M, int nc, int multi_label) {
+    size_t cap = (size_t)yolo_nms_capacity(M, nc, multi_label);
+    size_t ns = cap < MAX_NMS ? cap : MAX_NMS;
+    size_t words = (ns + 63) / 64;
+    size_t b = (size_t)bs * cap * 6 * 4;            // rows
+    b += (size_t)bs * MAX_NMS * 4;                  // order
+    b += ((size_t)bs * 4 + 4 + 15) / 16 * 16;       // count[bs] + overflow
+    b = (b + 15) / 16 * 16;
+    b += ns * words * 8;                            // mask (one image at a time)
+    return b;
+}
+
+// y: (bs, 4+nc, M) of dtype.  out: fp32 [bs][max_det][6] rows (x1,y1,x2,y2,conf,cls); out_count: int32 [bs];
+// status: int32[1], set to 1 if an image had more candidates than the capacity (result then invalid).
+int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, float iou_thres, const int* classes,
+             int n_classes, int agnostic, int multi_label, int max_det, float* out, int* out_count, int* status,
+             void* workspace, hipStream_t st) {
+    if (n_classes > 32 || max_det < 1) return YOLO_ERR_ARG;
+    const int cap = yolo_nms_capacity(M, nc, multi_label);
+    const int ns = cap < MAX_NMS ? cap : MAX_NMS;
+    const int words = (ns + 63) / 64;
+    char* ws = (char*)workspace;
+    float* rows = (float*)ws;
+    ws += (size_t)bs * cap * 6 * 4;
+    int* order = (int*)ws;
+    ws += (size_t)bs * MAX_NMS * 4;
+    int* count = (int*)ws;
+    int* overflow = count + bs;
+    ws += ((size_t)bs * 4 + 4 + 15) / 16 * 16;
+    ws = (char*)(((uintptr_t)ws + 15) / 16 * 16);
+    unsigned long long* mask = (unsigned long long*)ws;
+    ClsFilter filt;
+    filt.n = n_classes;
+    for (int k = 0; k < n_classes; ++k) filt.ids[k] = classes[k];
+    int rc = hip_status(hipMemsetAsync(overflow, 0, 4, st));
+    if (rc) return rc;
+    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_candidates<T>), dim3(bs), dim3(256), 0, st, (const T*)y, nc, M, conf_thres,
+                                              multi_label, filt, cap, rows, count, overflow));
+    hipLaunchKernelGGL(k_rank, dim3(ceil_div(cap, 256), bs), dim3(256), 0, st, rows, count, cap, order);
+    for (int img = 0; img < bs; ++img) {
+        hipLaunchKernelGGL(k_mask, dim3(words, words), dim3(64), 0, st, rows, count, order, cap, img, iou_thres, agnostic,
+                           words, mask);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(64), (size_t)words * 8, st, rows, count, order, cap, img, words, max_det,
+                           mask, out, out_count);
+    }
+    rc = hip_status(hipMemcpyAsync(status, overflow, 4, hipMemcpyDeviceToDevice, st));
+    if (rc) return rc;
+    return YOLO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

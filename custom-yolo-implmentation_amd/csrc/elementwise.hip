@@ -1,0 +1,613 @@
+// HBM-bound NHWC kernels: layout changes, channel copies, BatchNorm (+SiLU, +residual) forward and
+// backward, SPPF max-pool, nearest x2 upsample.  One 16-byte packet per lane wherever the channel
+// count allows it (guide: Guideline 13), fp32 arithmetic, fp32 statistics.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+template <typename T> __host__ bool vec_ok(const void* p, long ld, int C) {
+    constexpr int V = vec_of<T>::N;
+    return (C % V == 0) && (ld % V == 0) && ((reinterpret_cast<uintptr_t>(p) % 16) == 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (n, c, m) <-> NHWC tiled transposes.  "ncm" side: elem(n,c,p) at base[n*sn + c*sc + off + p].
+// ---------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void k_ncm_to_nhwc(const TI* __restrict__ src, long sn, long sc, long off,
+                              TO* __restrict__ dst, int ld, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows of 32
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? to_f<TI>(src[n * sn + c * sc + off + p]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int p = p0 + r, c = c0 + tx;
+        if (p < HW && c < C) dst[((long)n * HW + p) * ld + c] = from_f<TO>(tile[tx][r]);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void k_nhwc_to_ncm(const TI* __restrict__ src, int ld, TO* __restrict__ dst, long sn,
+                              long sc, long off, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? to_f<TI>(src[((long)n * HW + p) * ld + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) dst[n * sn + c * sc + off + p] = from_f<TO>(tile[tx][r]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel-slice copy / accumulate (concat, chunk backward, gradient fan-in)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V, bool ACC>
+__global__ void k_copy_channels(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd,
+                                long npix, int cv) {
+    long total = npix * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        float a[V];
+        load_pack<T, V>(src + p * lds_ + cg * V, a);
+        if (ACC) {
+            float b[V];
+            load_pack<T, V>(dst + p * ldd + cg * V, b);
+#pragma unroll
+            for (int j = 0; j < V; ++j) a[j] += b[j];
+        }
+        store_pack<T, V>(dst + p * ldd + cg * V, a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel reductions over pixels: partial[blk][2][C]
+//   MODE 0: (sum y, sum y^2)                      -- BN batch statistics / bias gradient
+//   MODE 1: (sum dz, sum dz*yhat), dz = dout*act'(z), z = y*scale+shift, yhat = (y-mean)*invstd
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == 0) return 1.f;
+    float s = sigmoidf_(z);
+    return s * (1.f + z * (1.f - s));
+}
+__device__ __forceinline__ float act_fwd(float z, int act) { return act == 0 ? z : z * sigmoidf_(z); }
+
+template <typename T, int V, int MODE>
+__global__ void k_channel_reduce(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                 long npix, int C, int act, float* __restrict__ partial) {
+    __shared__ float red[TPB][2 * V + 1];
+    const int cv = C / V;
+    const int tpr = cv < TPB ? cv : TPB;
+    const int rpb = TPB / tpr;
+    const int r = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    const bool active = (r < rpb) && (cg < cv);
+    float s[V], q[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
+    if (active) {
+        float sc[V], sh[V], mu[V], is[V];
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                sc[j] = scale[cg * V + j]; sh[j] = shift[cg * V + j];
+                mu[j] = mean[cg * V + j];  is[j] = invstd[cg * V + j];
+            }
+        }
+        for (long p = (long)blockIdx.x * rpb + r; p < npix; p += (long)gridDim.x * rpb) {
+            float a[V];
+            load_pack<T, V>(y + p * ldy + cg * V, a);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { s[j] += a[j]; q[j] += a[j] * a[j]; }
+            } else {
+                float d[V];
+                load_pack<T, V>(dout + p * ldd + cg * V, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float dz = d[j] * act_grad(a[j] * sc[j] + sh[j], act);
+                    s[j] += dz;
+                    q[j] += dz * ((a[j] - mu[j]) * is[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[threadIdx.x][j] = s[j]; red[threadIdx.x][V + j] = q[j]; }
+    __syncthreads();
+    if (r == 0 && cg < cv) {
+        for (int rr = 1; rr < rpb; ++rr) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s[j] += red[threadIdx.x + rr * tpr][j];
+                q[j] += red[threadIdx.x + rr * tpr][V + j];
+            }
+        }
+        float* o = partial + (long)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { o[cg * V + j] = s[j]; o[C + cg * V + j] = q[j]; }
+    }
+}
+
+// finalize for training-mode BN: batch mean / biased var -> invstd, scale, shift; running stats
+// updated with momentum and the unbiased variance (torch.nn.BatchNorm2d semantics).
+__global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, float count, int C,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                              float* __restrict__ mean, float* __restrict__ invstd,
+                              float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[(long)b * 2 * C + c]; q += partial[(long)b * 2 * C + C + c]; }
+    double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = is;
+    float g = gamma[c] * is;
+    scale[c] = g;
+    shift[c] = beta[c] - (float)m * g;
+    if (rmean) {
+        double unb = count > 1.f ? var * (count / (count - 1.0)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                 int C, float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = g;
+    shift[c] = beta[c] - rmean[c] * g;
+}
+
+// backward finalize: dgamma = sum dz*yhat, dbeta = sum dz, coef = [gamma*invstd, dbeta/m, dgamma/m]
+__global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, float count, int C,
+                                  const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[(long)b * 2 * C + c]; q += partial[(long)b * 2 * C + C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(s / count);
+    coef[2 * C + c] = (float)(q / count);
+}
+
+__global__ void k_sum_finalize(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 2 * C + c];
+    out[c] = (float)s;
+}
+
+// out = act(y*scale + shift) (+ res)
+template <typename T, int V>
+__global__ void k_bn_act_fwd(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                             const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                             T* __restrict__ out, int ldo, long npix, int cv, int act) {
+    long total = npix * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        float a[V];
+        load_pack<T, V>(y + p * ldy + cg * V, a);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * scale[cg * V + j] + shift[cg * V + j], act);
+        if (res) {
+            float r[V];
+            load_pack<T, V>(res + p * ldr + cg * V, r);
+#pragma unroll
+            for (int j = 0; j < V; ++j) a[j] += r[j];
+        }
+        store_pack<T, V>(out + p * ldo + cg * V, a);
+    }
+}
+
+// dy = k0*(dz - c1 - yhat*c2);  eval-style (coef == null): dy = scale*dz
+template <typename T, int V>
+__global__ void k_bn_act_bwd_apply(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
+                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                   const float* __restrict__ coef, T* __restrict__ dy, int lddy,
+                                   long npix, int C, int act) {
+    const int cv = C / V;
+    long total = npix * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        float a[V], d[V];
+        load_pack<T, V>(y + p * ldy + cg * V, a);
+        load_pack<T, V>(dout + p * ldd + cg * V, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            int c = cg * V + j;
+            float dz = d[j] * act_grad(a[j] * scale[c] + shift[c], act);
+            if (coef) {
+                float yh = (a[j] - mean[c]) * invstd[c];
+                d[j] = coef[c] * (dz - coef[C + c] - yh * coef[2 * C + c]);
+            } else {
+                d[j] = scale[c] * dz;
+            }
+        }
+        store_pack<T, V>(dy + p * lddy + cg * V, d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SPPF 5x5 stride-1 pad-2 max pool; idx = kh*5+kw of the FIRST maximum in window scan order
+// (ATen max_pool2d: strictly-greater update, NaN propagates) so ties route gradient identically.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void k_maxpool5_fwd(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo,
+                               uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+    const int cv = C / V;
+    long total = (long)N * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        int w = (int)(p % W);
+        long t = p / W;
+        int h = (int)(t % H);
+        long n = t / H;
+        float best[V];
+        int bi[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { best[j] = -INFINITY; bi[j] = -1; }
+        for (int kh = 0; kh < 5; ++kh) {
+            int hh = h + kh - 2;
+            if (hh < 0 || hh >= H) continue;
+            for (int kw = 0; kw < 5; ++kw) {
+                int ww = w + kw - 2;
+                if (ww < 0 || ww >= W) continue;
+                float a[V];
+                load_pack<T, V>(x + ((n * H + hh) * W + ww) * ldx + cg * V, a);
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    if (a[j] > best[j] || a[j] != a[j] || bi[j] < 0) { best[j] = a[j]; bi[j] = kh * 5 + kw; }
+            }
+        }
+        store_pack<T, V>(out + p * ldo + cg * V, best);
+#pragma unroll
+        for (int j = 0; j < V; ++j) idx[p * C + cg * V + j] = (uint8_t)bi[j];
+    }
+}
+
+// gather form of the backward: dx(p) = sum over the <=25 windows containing p whose argmax is p
+template <typename T, int V, bool ACC>
+__global__ void k_maxpool5_bwd(const T* __restrict__ dout, int ldd, const uint8_t* __restrict__ idx,
+                               T* __restrict__ dx, int ldx, int N, int H, int W, int C) {
+    const int cv = C / V;
+    long total = (long)N * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        int w = (int)(p % W);
+        long t = p / W;
+        int h = (int)(t % H);
+        long n = t / H;
+        float g[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = 0.f;
+        for (int kh = 0; kh < 5; ++kh) {
+            int oh = h - kh + 2;              // output row whose window tap kh lands on h
+            if (oh < 0 || oh >= H) continue;
+            for (int kw = 0; kw < 5; ++kw) {
+                int ow = w - kw + 2;
+                if (ow < 0 || ow >= W) continue;
+                long q = (n * H + oh) * W + ow;
+                float d[V];
+                load_pack<T, V>(dout + q * ldd + cg * V, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    if (idx[q * C + cg * V + j] == kh * 5 + kw) g[j] += d[j];
+            }
+        }
+        if (ACC) {
+            float b[V];
+            load_pack<T, V>(dx + p * ldx + cg * V, b);
+#pragma unroll
+            for (int j = 0; j < V; ++j) g[j] += b[j];
+        }
+        store_pack<T, V>(dx + p * ldx + cg * V, g);
+    }
+}
+
+// nearest x2 upsample: out(2H,2W); backward sums the 2x2 block
+template <typename T, int V>
+__global__ void k_upsample2x_fwd(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo,
+                                 int N, int H, int W, int C) {
+    const int cv = C / V;
+    const int OW = 2 * W, OH = 2 * H;
+    long total = (long)N * OH * OW * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        int ow = (int)(p % OW);
+        long t = p / OW;
+        int oh = (int)(t % OH);
+        long n = t / OH;
+        pack_t<T, V> v = *reinterpret_cast<const pack_t<T, V>*>(x + ((n * H + (oh >> 1)) * W + (ow >> 1)) * ldx + cg * V);
+        *reinterpret_cast<pack_t<T, V>*>(out + p * ldo + cg * V) = v;
+    }
+}
+
+template <typename T, int V, bool ACC>
+__global__ void k_upsample2x_bwd(const T* __restrict__ dout, int ldd, T* __restrict__ dx, int ldx,
+                                 int N, int H, int W, int C) {
+    const int cv = C / V;
+    const int OW = 2 * W, OH = 2 * H;
+    long total = (long)N * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        int w = (int)(p % W);
+        long t = p / W;
+        int h = (int)(t % H);
+        long n = t / H;
+        float g[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float d[V];
+                load_pack<T, V>(dout + ((n * OH + 2 * h + a) * OW + 2 * w + b) * ldd + cg * V, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j) g[j] += d[j];
+            }
+        if (ACC) {
+            float b2[V];
+            load_pack<T, V>(dx + p * ldx + cg * V, b2);
+#pragma unroll
+            for (int j = 0; j < V; ++j) g[j] += b2[j];
+        }
+        store_pack<T, V>(dx + p * ldx + cg * V, g);
+    }
+}
+
+inline int ew_grid(long total) {
+    long b = (total + TPB - 1) / TPB;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));   // <= 16 blocks per CU, grid-stride the rest
+}
+
+template <typename TI>
+int ncm_to_nhwc_out(const void* src, long sn, long sc, long off, void* dst, int dst_dtype, int ld, int N,
+                    int C, int HW, hipStream_t st) {
+    dim3 g(ceil_div(HW, 32), ceil_div(C, 32), N);
+    YOLO_DISPATCH_T(dst_dtype, hipLaunchKernelGGL((k_ncm_to_nhwc<TI, T>), g, dim3(256), 0, st, (const TI*)src,
+                                                  sn, sc, off, (T*)dst, ld, C, HW));
+    return YOLO_LAUNCH_CHECK();
+}
+template <typename TI>
+int nhwc_to_ncm_out(const void* src, int ld, void* dst, int dst_dtype, long sn, long sc, long off, int N,
+                    int C, int HW, hipStream_t st) {
+    dim3 g(ceil_div(HW, 32), ceil_div(C, 32), N);
+    YOLO_DISPATCH_T(dst_dtype, hipLaunchKernelGGL((k_nhwc_to_ncm<TI, T>), g, dim3(256), 0, st, (const TI*)src,
+                                                  ld, (T*)dst, sn, sc, off, C, HW));
+    return YOLO_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+#define PICK_V(T, ok, ...)                                       \
+    if (ok) { constexpr int V = vec_of<T>::N; __VA_ARGS__; }     \
+    else    { constexpr int V = 1; __VA_ARGS__; }
+
+extern "C" {
+
+int yolo_memset0(void* p, size_t bytes, hipStream_t st) { return hip_status(hipMemsetAsync(p, 0, bytes, st)); }
+
+int yolo_ncm_to_nhwc(const void* src, int src_dtype, long sn, long sc, long off, void* dst, int dst_dtype,
+                     int ld, int N, int C, int HW, hipStream_t st) {
+    switch (src_dtype) {
+        case YOLO_F32:  return ncm_to_nhwc_out<float>(src, sn, sc, off, dst, dst_dtype, ld, N, C, HW, st);
+        case YOLO_BF16: return ncm_to_nhwc_out<bf16_t>(src, sn, sc, off, dst, dst_dtype, ld, N, C, HW, st);
+        case YOLO_F16:  return ncm_to_nhwc_out<f16_t>(src, sn, sc, off, dst, dst_dtype, ld, N, C, HW, st);
+    }
+    return YOLO_ERR_DTYPE;
+}
+
+int yolo_nhwc_to_ncm(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, long sn, long sc,
+                     long off, int N, int C, int HW, hipStream_t st) {
+    switch (src_dtype) {
+        case YOLO_F32:  return nhwc_to_ncm_out<float>(src, ld, dst, dst_dtype, sn, sc, off, N, C, HW, st);
+        case YOLO_BF16: return nhwc_to_ncm_out<bf16_t>(src, ld, dst, dst_dtype, sn, sc, off, N, C, HW, st);
+        case YOLO_F16:  return nhwc_to_ncm_out<f16_t>(src, ld, dst, dst_dtype, sn, sc, off, N, C, HW, st);
+    }
+    return YOLO_ERR_DTYPE;
+}
+
+int yolo_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, long npix, int C, int accumulate,
+                       int dtype, hipStream_t st) {
+    if (npix <= 0 || C <= 0) return YOLO_OK;
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(src, ld_src, C) && vec_ok<T>(dst, ld_dst, C);
+        PICK_V(T, ok, {
+            int cv = C / V;
+            int g = ew_grid(npix * cv);
+            if (accumulate)
+                hipLaunchKernelGGL((k_copy_channels<T, V, true>), dim3(g), dim3(TPB), 0, st, (const T*)src, ld_src,
+                                   (T*)dst, ld_dst, npix, cv);
+            else
+                hipLaunchKernelGGL((k_copy_channels<T, V, false>), dim3(g), dim3(TPB), 0, st, (const T*)src, ld_src,
+                                   (T*)dst, ld_dst, npix, cv);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+// number of partial blocks yolo_bn_stats / yolo_bn_act_bwd_reduce will write for this problem
+int yolo_reduce_nblk(long npix, int C) {
+    long want = npix / 64;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    return (int)want;
+}
+
+static int launch_reduce(int mode, const void* y, int ldy, const void* dout, int ldd, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, long npix, int C, int act,
+                         int dtype, float* partial, int nblk, hipStream_t st) {
+    if (nblk != yolo_reduce_nblk(npix, C)) return YOLO_ERR_ARG;
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(y, ldy, C) && (mode == 0 || vec_ok<T>(dout, ldd, C));
+        PICK_V(T, ok, {
+            int cv = C / V;
+            int tpr = cv < TPB ? cv : TPB;
+            dim3 g(nblk, ceil_div(cv, tpr));
+            if (mode == 0)
+                hipLaunchKernelGGL((k_channel_reduce<T, V, 0>), g, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)nullptr,
+                                   0, scale, shift, mean, invstd, npix, C, act, partial);
+            else
+                hipLaunchKernelGGL((k_channel_reduce<T, V, 1>), g, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)dout,
+                                   ldd, scale, shift, mean, invstd, npix, C, act, partial);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_stats(const void* y, int ldy, long npix, int C, int dtype, float* partial, int nblk, hipStream_t st) {
+    return launch_reduce(0, y, ldy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, npix, C, 0, dtype, partial, nblk, st);
+}
+
+int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                     float* invstd, float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 128)), dim3(128), 0, st, partial, nblk, (float)count, C, gamma,
+                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ceil_div(C, 128)), dim3(128), 0, st, gamma, beta, running_mean,
+                       running_var, eps, C, scale, shift);
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_sum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_finalize, dim3(ceil_div(C, 128)), dim3(128), 0, st, partial, nblk, C, out);
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres,
+                    void* out, int ldout, long npix, int C, int act, int dtype, hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(out, ldout, C) && (!res || vec_ok<T>(res, ldres, C));
+        PICK_V(T, ok, {
+            int cv = C / V;
+            hipLaunchKernelGGL((k_bn_act_fwd<T, V>), dim3(ew_grid(npix * cv)), dim3(TPB), 0, st, (const T*)y, ldy, scale,
+                               shift, (const T*)res, ldres, (T*)out, ldout, npix, cv, act);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_act_bwd_reduce(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, long npix, int C, int act, int dtype,
+                           float* partial, int nblk, hipStream_t st) {
+    return launch_reduce(1, y, ldy, dout, ldd, scale, shift, mean, invstd, npix, C, act, dtype, partial, nblk, st);
+}
+
+int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* invstd,
+                         float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 128)), dim3(128), 0, st, partial, nblk, (float)count, C,
+                       gamma, invstd, dgamma, dbeta, coef);
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* coef, void* dy, int lddy, long npix,
+                          int C, int act, int dtype, hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(dout, ldd, C) && vec_ok<T>(dy, lddy, C);
+        PICK_V(T, ok, {
+            int cv = C / V;
+            hipLaunchKernelGGL((k_bn_act_bwd_apply<T, V>), dim3(ew_grid(npix * cv)), dim3(TPB), 0, st, (const T*)dout,
+                               ldd, (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, npix, C, act);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_maxpool5_fwd(const void* x, int ldx, void* out, int ldo, uint8_t* idx, int N, int H, int W, int C,
+                      int dtype, hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(x, ldx, C) && vec_ok<T>(out, ldo, C);
+        PICK_V(T, ok, {
+            hipLaunchKernelGGL((k_maxpool5_fwd<T, V>), dim3(ew_grid((long)N * H * W * (C / V))), dim3(TPB), 0, st,
+                               (const T*)x, ldx, (T*)out, ldo, idx, N, H, W, C);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_maxpool5_bwd(const void* dout, int ldd, const uint8_t* idx, void* dx, int ldx, int N, int H, int W, int C,
+                      int accumulate, int dtype, hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(dout, ldd, C) && vec_ok<T>(dx, ldx, C);
+        PICK_V(T, ok, {
+            int g = ew_grid((long)N * H * W * (C / V));
+            if (accumulate)
+                hipLaunchKernelGGL((k_maxpool5_bwd<T, V, true>), dim3(g), dim3(TPB), 0, st, (const T*)dout, ldd, idx,
+                                   (T*)dx, ldx, N, H, W, C);
+            else
+                hipLaunchKernelGGL((k_maxpool5_bwd<T, V, false>), dim3(g), dim3(TPB), 0, st, (const T*)dout, ldd, idx,
+                                   (T*)dx, ldx, N, H, W, C);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_upsample2x_fwd(const void* x, int ldx, void* out, int ldo, int N, int H, int W, int C, int dtype,
+                        hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(x, ldx, C) && vec_ok<T>(out, ldo, C);
+        PICK_V(T, ok, {
+            hipLaunchKernelGGL((k_upsample2x_fwd<T, V>), dim3(ew_grid((long)N * 4 * H * W * (C / V))), dim3(TPB), 0, st,
+                               (const T*)x, ldx, (T*)out, ldo, N, H, W, C);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_upsample2x_bwd(const void* dout, int ldd, void* dx, int ldx, int N, int H, int W, int C, int accumulate,
+                        int dtype, hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(dout, ldd, C) && vec_ok<T>(dx, ldx, C);
+        PICK_V(T, ok, {
+            int g = ew_grid((long)N * H * W * (C / V));
+            if (accumulate)
+                hipLaunchKernelGGL((k_upsample2x_bwd<T, V, true>), dim3(g), dim3(TPB), 0, st, (const T*)dout, ldd,
+                                   (T*)dx, ldx, N, H, W, C);
+            else
+                hipLaunchKernelGGL((k_upsample2x_bwd<T, V, false>), dim3(g), dim3(TPB), 0, st, (const T*)dout, ldd,
+                                   (T*)dx, ldx, N, H, W, C);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

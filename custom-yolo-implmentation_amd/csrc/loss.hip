@@ -1,0 +1,332 @@
+// YoloDFLQFLoss forward + gradient in one pass over preds (reference src/model/losses.py:140-281).
+//
+//   preds  [N][64+nc][A]  (T, anchor index fastest)  ->  out[3] = {total, mean_dfl, mean_cls} (fp32)
+//                                                        dpreds [N][64+nc][A] (T) = d total / d preds
+// Launch chain (one stream):
+//   k_decode   : per (n,a) softmax-expectation of the 4x16 DFL logits -> centre-xywh pixels (fp32 pbox)
+//   k_assign   : per GT, argmin over anchors of the distance to the predicted centre, evaluated the way
+//                torch.cdist does for >25 columns ( |a|^2 + |b|^2 - 2ab via a k-ordered fma chain,
+//                clamp, sqrt ) so near-ties resolve as in the reference; first minimum wins
+//   k_dense    : quality-focal term with an all-zero target for every class logit (+ its gradient),
+//                zero gradient for the 64 box logits; per-block partial sums (deterministic)
+//   k_matched  : per image, per matched anchor: DFL cross-entropy pair and its gradient, the quirk IoU
+//                (b1_y2 = h + cy/2, losses.py:20), the soft target at (anchor, class) of the LAST GT
+//                mapped there (losses.py:261), and the IoU gradient that autograd hands to EVERY GT
+//                (also those that lost the slot) back through box decode into the box logits
+//   k_finish   : partials -> the three scalars
+// fp32 arithmetic, no fma contraction in this file (built with -ffp-contract=off) so the box decode
+// follows the reference's operation order.
+#include "common.h"
+
+namespace {
+
+constexpr int REG = 16;
+constexpr float QEPS = 1e-12f;
+
+struct LossDims {
+    int N, A, nc;
+    float lambda_dfl, lambda_cls;
+};
+
+template <typename T>
+__global__ void k_decode(LossDims d, const T* __restrict__ preds, const T* __restrict__ anchors,
+                         const T* __restrict__ strides, float4* __restrict__ pbox) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)d.N * d.A) return;
+    int a = (int)(i % d.A);
+    long n = i / d.A;
+    const T* p = preds + n * (long)(4 * REG + d.nc) * d.A + a;
+    float e[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float x[REG], mx = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < REG; ++b) { x[b] = to_f<T>(p[(long)(s * REG + b) * d.A]); mx = fmaxf(mx, x[b]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < REG; ++b) { x[b] = expf(x[b] - mx); sum += x[b]; }
+        float ex = 0.f;
+#pragma unroll
+        for (int b = 0; b < REG; ++b) ex += (x[b] / sum) * (float)b;
+        e[s] = ex;
+    }
+    float ax = to_f<T>(anchors[a]), ay = to_f<T>(anchors[d.A + a]), st = to_f<T>(strides[a]);
+    float x1 = (ax - e[0]) * st, y1 = (ay - e[1]) * st, x2 = (ax + e[2]) * st, y2 = (ay + e[3]) * st;
+    pbox[i] = make_float4((x1 + x2) / 2.f, (y1 + y2) / 2.f, x2 - x1, y2 - y1);
+}
+
+__global__ void k_assign(int A, const float4* __restrict__ pbox, const float* __restrict__ gt,
+                         const int* __restrict__ gt_img, int* __restrict__ idx) {
+    __shared__ float sd[4];
+    __shared__ int si[4];
+    const int j = blockIdx.x;
+    const float gx = gt[j * 5 + 0], gy = gt[j * 5 + 1];
+    const float4* pb = pbox + (long)gt_img[j] * A;
+    const float an = __fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy));
+    const float m2x = -2.f * gx, m2y = -2.f * gy;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        float4 b = pb[a];
+        float bn = __fadd_rn(__fmul_rn(b.x, b.x), __fmul_rn(b.y, b.y));
+        float acc = __fmul_rn(m2x, b.x);
+        acc = __fmaf_rn(m2y, b.y, acc);
+        acc = __fadd_rn(an, acc);
+        acc = __fadd_rn(bn, acc);
+        float dist = __fsqrt_rn(fmaxf(acc, 0.f));
+        if (dist < best || (dist != dist && best == best)) { best = dist; bi = a; }   // NaN wins like argmin
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        bool take = (ob < best) || (ob == best && oi < bi) || (ob != ob && (best == best || oi < bi));
+        if (take) { best = ob; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            float ob = sd[w];
+            int oi = si[w];
+            bool take = (ob < best) || (ob == best && oi < bi) || (ob != ob && (best == best || oi < bi));
+            if (take) { best = ob; bi = oi; }
+        }
+        idx[j] = bi;
+    }
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// QFL element with target t: value and d/dlogit (losses.py:51-55)
+__device__ __forceinline__ void qfl_elem(float x, float t, float& val, float& dx) {
+    float s = sigm(x);
+    float ls = logf(s + QEPS), l1 = logf(1.f - s + QEPS);
+    float om = 1.f - s;
+    val = -(t * om * om * ls + (1.f - t) * s * s * l1);
+    float dpos = -2.f * om * ls + om * om / (s + QEPS);
+    float dneg = 2.f * s * l1 - s * s / (1.f - s + QEPS);
+    dx = -(t * dpos + (1.f - t) * dneg) * s * om;
+}
+
+template <typename T, int V>
+__global__ void k_dense(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds, float coef,
+                        double* __restrict__ partial) {
+    __shared__ float red[4];
+    const int Cp = 4 * REG + d.nc;
+    const long per_n = (long)Cp * d.A;
+    const long total = (long)d.N * per_n / V;
+    float lsum = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long e0 = i * V;
+        int c = (int)((e0 % per_n) / d.A);
+        float g[V];
+        if (c < 4 * REG) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] = 0.f;
+        } else {
+            float x[V];
+            load_pack<T, V>(preds + e0, x);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float v, dx;
+                qfl_elem(x[k], 0.f, v, dx);
+                lsum += v;
+                g[k] = dx * coef;
+            }
+        }
+        if (dpreds) store_pack<T, V>(dpreds + e0, g);
+    }
+    lsum = wave_sum(lsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (double)red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup per image; wave w takes GTs w, w+4, ...; lane = (side, bin) of the 64 box logits
+template <typename T>
+__global__ __launch_bounds__(256) void k_matched(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds,
+                                                 const T* __restrict__ anchors, const T* __restrict__ strides,
+                                                 const float4* __restrict__ pbox, const float* __restrict__ gt,
+                                                 const int* __restrict__ gt_off, const int* __restrict__ idx,
+                                                 double* __restrict__ img_dfl, double* __restrict__ img_cls_fix) {
+    __shared__ double w_dfl[4], w_cls[4];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g0 = gt_off[n], M = gt_off[n + 1] - g0;
+    const int Cp = 4 * REG + d.nc;
+    const T* pn = preds + (long)n * Cp * d.A;
+    T* dn = dpreds ? dpreds + (long)n * Cp * d.A : nullptr;
+    const int side = lane >> 4, bin = lane & 15;
+    const float cdfl = d.lambda_dfl / (float)d.N * 0.25f / (float)(M > 0 ? M : 1);
+    const float ccls = d.lambda_cls / (float)d.N / (float)d.A;
+    double acc_dfl = 0.0, acc_cls = 0.0;
+
+    for (int j = wave; j < M; j += 4) {
+        const int a = idx[g0 + j];
+        bool owner = true;
+        for (int q = 0; q < j; ++q) owner &= (idx[g0 + q] != a);
+        if (!owner) continue;                                   // wave-uniform
+        // softmax of this lane's side over its 16 bins
+        float x = to_f<T>(pn[(long)lane * d.A + a]);
+        float mx = x;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float ex = expf(x - mx), sum = ex;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        float p = ex / sum, lse = mx + logf(sum);
+        float ev = p * (float)bin;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ev += __shfl_xor(ev, o, 64);           // expectation of my side
+        const float ax = to_f<T>(anchors[a]), ay = to_f<T>(anchors[d.A + a]), st = to_f<T>(strides[a]);
+        const float4 pb = pbox[(long)n * d.A + a];
+        float gacc = 0.f;                                        // d total / d logit(lane)
+        int winner = -1;
+        for (int q = j; q < M; ++q)
+            if (idx[g0 + q] == a) winner = q;
+        for (int q = j; q < M; ++q) {
+            if (idx[g0 + q] != a) continue;
+            const float* gq = gt + (long)(g0 + q) * 5;
+            const float gx = gq[0], gy = gq[1], gw = gq[2], gh = gq[3];
+            const int cls = (int)gq[4];
+            const float gx1 = gx - gw / 2.f, gy1 = gy - gh / 2.f, gx2 = gx + gw / 2.f, gy2 = gy + gh / 2.f;
+            // ---- DFL (losses.py:226-253)
+            float tl = ax - gx1 / st, tt = ay - gy1 / st, tr = gx2 / st - ax, tb = gy2 / st - ay;
+            float tv = side == 0 ? tl : side == 1 ? tt : side == 2 ? tr : tb;
+            tv = fminf(fmaxf(tv, 0.f), (float)(REG - 1) - 0.01f);
+            int lo = (int)tv;
+            float wl = (float)(lo + 1) - tv, wr = tv - (float)lo;
+            float contrib = (bin == lo ? wl * (lse - x) : 0.f) + (bin == lo + 1 ? wr * (lse - x) : 0.f);
+            float side_loss = contrib;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) side_loss += __shfl_xor(side_loss, o, 64);
+            float all_sides = side_loss + __shfl_xor(side_loss, 16, 64);
+            all_sides += __shfl_xor(all_sides, 32, 64);
+            if (lane == 0) acc_dfl += (double)all_sides * 0.25 / (double)M;
+            gacc += cdfl * (p - (bin == lo ? wl : 0.f) - (bin == lo + 1 ? wr : 0.f));
+            // ---- quirk IoU of (pred box, GT) and its gradient (losses.py:17-40)
+            const float X1 = pb.x - pb.z / 2.f, Y1 = pb.y - pb.w / 2.f, X2 = pb.x + pb.z / 2.f, Y2 = pb.w + pb.y / 2.f;
+            const float iwr = fminf(X2, gx2) - fmaxf(X1, gx1), ihr = fminf(Y2, gy2) - fmaxf(Y1, gy1);
+            const float iw = fmaxf(iwr, 0.f), ih = fmaxf(ihr, 0.f);
+            const float inter = iw * ih;
+            const float a1 = (X2 - X1) * (Y2 - Y1), a2 = (gx2 - gx1) * (gy2 - gy1);
+            const float den = a1 + a2 - inter + 1e-6f;
+            const float iou = inter / den;
+            // class logit of this GT at the matched anchor
+            const float xc = to_f<T>(pn[(long)(4 * REG + cls) * d.A + a]);
+            const float sc = sigm(xc);
+            const float omc = 1.f - sc;
+            // d total / d iou  (QFL is linear in the target)
+            const float giou = ccls * -(omc * omc * logf(sc + QEPS) - sc * sc * logf(1.f - sc + QEPS));
+            // min/max split a tie evenly, clamp(min=0) passes gradient at >= 0 (ATen semantics)
+            const float mX2 = X2 < gx2 ? 1.f : (X2 == gx2 ? 0.5f : 0.f), mX1 = X1 > gx1 ? 1.f : (X1 == gx1 ? 0.5f : 0.f);
+            const float mY2 = Y2 < gy2 ? 1.f : (Y2 == gy2 ? 0.5f : 0.f), mY1 = Y1 > gy1 ? 1.f : (Y1 == gy1 ? 0.5f : 0.f);
+            const float pw = iwr >= 0.f ? 1.f : 0.f, ph = ihr >= 0.f ? 1.f : 0.f;
+            const float dI_X2 = ih * pw * mX2, dI_X1 = -ih * pw * mX1, dI_Y2 = iw * ph * mY2, dI_Y1 = -iw * ph * mY1;
+            const float dA_X2 = (Y2 - Y1), dA_X1 = -(Y2 - Y1), dA_Y2 = (X2 - X1), dA_Y1 = -(X2 - X1);
+            const float kI = 1.f / den + inter / (den * den), kA = inter / (den * den);
+            const float dX1 = giou * (kI * dI_X1 - kA * dA_X1), dX2 = giou * (kI * dI_X2 - kA * dA_X2);
+            const float dY1 = giou * (kI * dI_Y1 - kA * dA_Y1), dY2 = giou * (kI * dI_Y2 - kA * dA_Y2);
+            const float dcx = dX1 + dX2, dw = (dX2 - dX1) / 2.f, dcy = dY1 + dY2 / 2.f, dh = dY2 - dY1 / 2.f;
+            const float dx1 = dcx / 2.f - dw, dx2 = dcx / 2.f + dw, dy1 = dcy / 2.f - dh, dy2 = dcy / 2.f + dh;
+            const float gs = side == 0 ? -st * dx1 : side == 1 ? -st * dy1 : side == 2 ? st * dx2 : st * dy2;
+            gacc += gs * p * ((float)bin - ev);
+            // ---- soft target fix-up at (a, cls) for the GT that owns the slot (last one wins)
+            if (q == winner && lane == 0) {
+                float v0, g0_, v1, g1_;
+                qfl_elem(xc, 0.f, v0, g0_);
+                qfl_elem(xc, iou, v1, g1_);
+                acc_cls += (double)v1 - (double)v0;
+                if (dn) dn[(long)(4 * REG + cls) * d.A + a] = from_f<T>(g1_ * ccls);
+            }
+        }
+        if (dn) dn[(long)lane * d.A + a] = from_f<T>(gacc);
+    }
+    if (lane == 0) { w_dfl[wave] = acc_dfl; w_cls[wave] = acc_cls; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        img_dfl[n] = w_dfl[0] + w_dfl[1] + w_dfl[2] + w_dfl[3];
+        img_cls_fix[n] = w_cls[0] + w_cls[1] + w_cls[2] + w_cls[3];
+    }
+}
+
+__global__ void k_finish(LossDims d, const double* __restrict__ partial, int nblk, const double* __restrict__ img_dfl,
+                         const double* __restrict__ img_cls_fix, float* __restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    double cls = 0.0, dfl = 0.0;
+    for (int b = 0; b < nblk; ++b) cls += partial[b];
+    for (int n = 0; n < d.N; ++n) { cls += img_cls_fix[n]; dfl += img_dfl[n]; }
+    double mean_cls = cls / (double)d.A / (double)d.N, mean_dfl = dfl / (double)d.N;
+    out[0] = (float)(d.lambda_dfl * mean_dfl + d.lambda_cls * mean_cls);
+    out[1] = (float)mean_dfl;
+    out[2] = (float)mean_cls;
+}
+
+template <typename T>
+__global__ void k_scale(T* __restrict__ x, long n, const float* __restrict__ s) {
+    const float f = *s;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] = from_f<T>(to_f<T>(x[i]) * f);
+}
+
+constexpr int DENSE_BLOCKS = 2048;
+
+}  // namespace
+
+extern "C" {
+
+// workspace bytes: pbox (16 B per anchor) + idx (4 B per GT) + partials
+size_t yolo_loss_workspace_bytes(int N, int A, int G) {
+    size_t b = (size_t)N * A * 16;
+    b += ((size_t)(G > 0 ? G : 1) * 4 + 15) / 16 * 16;
+    b += (size_t)(DENSE_BLOCKS + 2 * N) * 8;
+    return b;
+}
+
+// gt: fp32 [G][5] (cx,cy,w,h,cls, pixels) grouped by image; gt_off: int32 [N+1]; gt_img: int32 [G].
+// dpreds may be null (validation).  out: fp32[3] = {total, mean_dfl ("box_loss"), mean_cls}.
+int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A,
+                      const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl,
+                      float lambda_cls, void* dpreds, float* out, void* workspace, hipStream_t st) {
+    LossDims d{N, A, nc, lambda_dfl, lambda_cls};
+    char* ws = (char*)workspace;
+    float4* pbox = (float4*)ws;
+    ws += (size_t)N * A * 16;
+    int* idx = (int*)ws;
+    ws += ((size_t)(G > 0 ? G : 1) * 4 + 15) / 16 * 16;
+    double* partial = (double*)ws;
+    double* img_dfl = partial + DENSE_BLOCKS;
+    double* img_fix = img_dfl + N;
+    const long NA = (long)N * A;
+    const long elems = NA * (64 + nc);
+    const float coef = lambda_cls / (float)N / (float)A;
+    YOLO_DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((k_decode<T>), dim3(ceil_div(NA, 256)), dim3(256), 0, st, d, (const T*)preds,
+                           (const T*)anchors, (const T*)strides, pbox);
+        if (G > 0) hipLaunchKernelGGL(k_assign, dim3(G), dim3(256), 0, st, A, pbox, gt, gt_img, idx);
+        constexpr int VV = vec_of<T>::N;
+        bool vec = (A % VV == 0) && ((uintptr_t)preds % 16 == 0) && (!dpreds || (uintptr_t)dpreds % 16 == 0);
+        int nblk = (int)((elems / (vec ? VV : 1) + 255) / 256);
+        if (nblk > DENSE_BLOCKS) nblk = DENSE_BLOCKS;
+        if (nblk < 1) nblk = 1;
+        int rc = hip_status(hipMemsetAsync(partial, 0, DENSE_BLOCKS * sizeof(double), st));
+        if (rc) return rc;
+        if (vec) hipLaunchKernelGGL((k_dense<T, VV>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial);
+        else hipLaunchKernelGGL((k_dense<T, 1>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial);
+        hipLaunchKernelGGL((k_matched<T>), dim3(N), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, (const T*)anchors,
+                           (const T*)strides, pbox, gt, gt_off, idx, img_dfl, img_fix);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, d, partial, DENSE_BLOCKS, img_dfl, img_fix, out);
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+// x *= *scale_dev (scale read on the device: no host sync); used to apply the incoming grad_output
+int yolo_scale_inplace(void* x, long n, int dtype, const float* scale_dev, hipStream_t st) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_scale<T>), dim3((int)b), dim3(256), 0, st, (T*)x, n, scale_dev));
+    return YOLO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

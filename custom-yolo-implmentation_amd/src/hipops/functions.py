@@ -1,0 +1,300 @@
+"""torch.autograd Functions over the HIP leaf ops (ops.py).  Each Function is the fused unit the
+reference spells as several ATen ops; the forward saves exactly what its hand-written backward needs.
+All leaf calls go through the `ops` module namespace (tests swap leaves for a torch emulation to check
+this wiring on a machine without a GPU; the product never does)."""
+import torch
+
+from . import ops
+from .lib import ACT_IDENTITY, ACT_SILU  # noqa: F401
+
+_LOWP = (torch.bfloat16, torch.float16)
+
+
+def compute_dtype(x, w):
+    """Element type the block computes in: the autocast dtype when autocast is on (DDP mode of the
+    reference, src/training/train_model.py:240-243), else the parameters' low-precision dtype (FSDP
+    mixed precision casts them, src/training/utils_train.py:84-89,146-149), else the input's."""
+    dev = x.device.type
+    if torch.is_autocast_enabled(dev):
+        return torch.get_autocast_dtype(dev)
+    if w.dtype in _LOWP:
+        return w.dtype
+    return x.dtype if x.dtype in (torch.float32,) + _LOWP else torch.float32
+
+
+def _as_nhwc(t, dtype):
+    return t if (t.dtype == dtype and ops.is_nhwc(t)) else ops.to_nhwc(t, dtype)
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+class ConvBnAct(torch.autograd.Function):
+    """act(BN(conv(x))) (+ residual).  Reference: Conv.forward, src/model/model_blocks.py:31-34; the
+    residual adds of Residual/PSABlock (:62, :223-224) ride in the same epilogue.
+    groups is 1 or C (depthwise 3x3)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps):
+        T = compute_dtype(x, weight)
+        x = _as_nhwc(x, T)
+        cout = weight.shape[0]
+        if depthwise:
+            w9 = _f32(weight).reshape(cout, 9)
+            y = ops.dw_fwd(x, w9)
+        else:
+            y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride)
+        g32, b32 = _f32(gamma), _f32(beta)
+        rm, rv = bufs
+        if training:
+            rm32, rv32 = _f32(rm), _f32(rv)
+            mean, invstd, scale, shift = ops.bn_train_stats(y, g32, b32, rm32, rv32, momentum, eps)
+            if rm32 is not rm:
+                rm.copy_(rm32)
+                rv.copy_(rv32)
+        else:
+            mean = invstd = None
+            scale, shift = ops.bn_eval_coeffs(g32, b32, _f32(rm), _f32(rv), eps)
+        if res is not None:
+            res = _as_nhwc(res, T)
+        out = ops.bn_act_fwd(y, scale, shift, act, res)
+        ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype)
+        ctx.save_for_backward(x, weight, y, scale, shift, mean, invstd, g32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, stride, depthwise, act, training, xshape, has_res, gdtype = ctx.cfg
+        x, weight, y, scale, shift, mean, invstd, g32 = ctx.saved_tensors
+        T = y.dtype
+        dout = _as_nhwc(dout, T)
+        if training:
+            dy, dgamma, dbeta = ops.bn_act_bwd(dout, y, scale, shift, mean, invstd, g32, act)
+        else:
+            dy, dgamma, dbeta = ops.bn_act_bwd_eval(dout, y, scale, shift, act), None, None
+        dx = dw = None
+        n, cin, h, w = xshape
+        if depthwise:
+            if ctx.needs_input_grad[0]:
+                dx = ops.dw_dgrad(dy, _f32(weight).reshape(weight.shape[0], 9))
+            if ctx.needs_input_grad[1]:
+                dw = ops.dw_wgrad(x, dy).to(weight.dtype)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride)
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv_wgrad(x, dy, k, stride, weight.dtype)
+        if dgamma is not None and ctx.needs_input_grad[2]:
+            dgamma, dbeta = dgamma.to(gdtype), dbeta.to(gdtype)
+        else:
+            dgamma = dbeta = None
+        dres = dout if (has_res and ctx.needs_input_grad[4]) else None
+        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+class ConvBias(torch.autograd.Function):
+    """Plain dense conv + bias: the head's final nn.Conv2d 1x1 (src/model/head.py:50,60)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k, stride):
+        T = compute_dtype(x, weight)
+        x = _as_nhwc(x, T)
+        cout = weight.shape[0]
+        b32 = _f32(bias) if bias is not None else None
+        y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), b32, cout, k, stride)
+        ctx.cfg = (k, stride, tuple(x.shape), None if bias is None else bias.dtype)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k, stride, xshape, bdtype = ctx.cfg
+        x, weight = ctx.saved_tensors
+        dy = _as_nhwc(dy, x.dtype)
+        n, cin, h, w = xshape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, x.dtype), cin, h, w, k, stride)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, dy, k, stride, weight.dtype)
+        if bdtype is not None and ctx.needs_input_grad[2]:
+            db = ops.channel_sum(dy).to(bdtype)
+        return dx, dw, db, None, None
+
+
+def fused_conv_act(x, weight, bias, k, stride, depthwise, act, res=None):
+    """Conv with BN folded in (Model.fuse(), src/model/model_blocks.py:36-37): act(conv(x) + b) (+ res).
+    Inference-only like the reference's fused conv (requires_grad False); no autograd node."""
+    with torch.no_grad():
+        T = compute_dtype(x, weight)
+        x = _as_nhwc(x, T)
+        cout = weight.shape[0]
+        b32 = _f32(bias)
+        if not depthwise and act == ACT_IDENTITY and res is None:
+            return ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), b32, cout, k, stride)
+        if depthwise:
+            y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9))
+        else:
+            y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride)
+        one = ops.fill_(torch.empty(cout, dtype=torch.float32, device=x.device), 1.0)
+        return ops.bn_act_fwd(y, one, b32, act, None if res is None else _as_nhwc(res, T))
+
+
+class Cat(torch.autograd.Function):
+    """torch.cat(dim=1) as channel-slice copies into one NHWC buffer; backward hands out slices."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        T = xs[0].dtype
+        xs = [_as_nhwc(x, T) for x in xs]
+        n, _, h, w = xs[0].shape
+        cs = [x.shape[1] for x in xs]
+        out = ops.new_nhwc(n, sum(cs), h, w, T, xs[0].device)
+        off = 0
+        for x, c in zip(xs, cs):
+            ops.copy_channels(x, out[:, off:off + c])
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _as_nhwc(dout, dout.dtype)
+        grads, off = [], 0
+        for c in ctx.cs:
+            grads.append(dout[:, off:off + c])
+            off += c
+        return tuple(grads)
+
+
+class Chunk2(torch.autograd.Function):
+    """x.chunk(2, 1): two channel-slice views; backward re-assembles the halves (zeros where unused)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _as_nhwc(x, x.dtype)
+        h = x.shape[1] // 2
+        ctx.shape = tuple(x.shape)
+        return x[:, :h], x[:, h:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        n, c, h, w = ctx.shape
+        ref = g0 if g0 is not None else g1
+        dx = ops.new_nhwc(n, c, h, w, ref.dtype, ref.device)
+        half = c // 2
+        for g, sl in ((g0, dx[:, :half]), (g1, dx[:, half:])):
+            if g is None:
+                ops.copy_channels(ops.zero_(ops.new_nhwc(n, sl.shape[1], h, w, ref.dtype, ref.device)), sl)
+            else:
+                ops.copy_channels(_as_nhwc(g, ref.dtype), sl)
+        return dx
+
+
+class MaxPool5(torch.autograd.Function):
+    """nn.MaxPool2d(5, 1, 2) (src/model/model_blocks.py:150)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out, idx = ops.maxpool5_fwd(_as_nhwc(x, x.dtype))
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool5_bwd(_as_nhwc(dout, dout.dtype), idx)
+
+
+class Upsample2x(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2), nearest (src/model/neck.py:31)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x_fwd(_as_nhwc(x, x.dtype))
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.upsample2x_bwd(_as_nhwc(dout, dout.dtype))
+
+
+class AttentionCore(torch.autograd.Function):
+    """softmax(q^T k * scale) applied to v, per head, plus v re-gathered for the positional dw-conv
+    (src/model/model_blocks.py:190-197).  qkv is the NHWC output of the qkv Conv."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, dk, dh, scale):
+        qkv = _as_nhwc(qkv, qkv.dtype)
+        o, vp, lse = ops.attn_fwd(qkv, heads, dk, dh, scale)
+        ctx.cfg = (heads, dk, dh, scale)
+        ctx.save_for_backward(qkv, o, lse)
+        return o, vp
+
+    @staticmethod
+    def backward(ctx, d_o, d_vp):
+        heads, dk, dh, scale = ctx.cfg
+        qkv, o, lse = ctx.saved_tensors
+        T = qkv.dtype
+        if d_o is None:
+            d_o = ops.zero_(ops.new_nhwc(*o.shape, T, o.device))
+        d_o = _as_nhwc(d_o, T)
+        d_vp = _as_nhwc(d_vp, T) if d_vp is not None else None
+        return ops.attn_bwd(qkv, o, d_o, d_vp, lse, heads, dk, dh, scale), None, None, None, None
+
+
+class HeadPack(torch.autograd.Function):
+    """cat(box, cls) per level -> view(N, no, -1) -> cat over levels (src/model/head.py:87,119):
+    NHWC branch outputs are transposed straight into the (N, 64+nc, M) prediction tensor."""
+
+    @staticmethod
+    def forward(ctx, *branches):
+        T = branches[0].dtype
+        branches = [_as_nhwc(b, T) for b in branches]
+        n = branches[0].shape[0]
+        levels = [(branches[i], branches[i + 1]) for i in range(0, len(branches), 2)]
+        no = levels[0][0].shape[1] + levels[0][1].shape[1]
+        m = sum(b.shape[2] * b.shape[3] for b, _ in levels)
+        preds = torch.empty((n, no, m), dtype=T, device=branches[0].device)
+        meta, m_off = [], 0
+        for box, cls in levels:
+            h, w = box.shape[2], box.shape[3]
+            ops.head_pack(box, preds, 0, m_off)
+            ops.head_pack(cls, preds, box.shape[1], m_off)
+            meta.append((box.shape[1], cls.shape[1], h, w, m_off))
+            m_off += h * w
+        ctx.meta = meta
+        return preds
+
+    @staticmethod
+    def backward(ctx, dpreds):
+        dpreds = dpreds.contiguous()
+        grads = []
+        for cb, cc, h, w, m_off in ctx.meta:
+            grads.append(ops.head_unpack(dpreds, 0, cb, m_off, h, w))
+            grads.append(ops.head_unpack(dpreds, cb, cc, m_off, h, w))
+        return tuple(grads)
+
+
+class DflQflLoss(torch.autograd.Function):
+    """YoloDFLQFLoss value and gradient from one fused pass (src/model/losses.py:140-281).
+    Returns (total, scalars[3]); scalars = (total, mean_dfl, mean_cls) detached."""
+
+    @staticmethod
+    def forward(ctx, preds, anchors, strides, packed, nc, lambda_dfl, lambda_cls):
+        gt, gt_off, gt_img, n_gt = packed
+        want = ctx.needs_input_grad[0]
+        out, dpreds, _ = ops.loss_fwd_bwd(preds.contiguous(), anchors, strides, gt, gt_off, gt_img, n_gt, nc,
+                                          lambda_dfl, lambda_cls, want)
+        ctx.dpreds = dpreds
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_scalars):
+        dpreds = ctx.dpreds
+        ctx.dpreds = None
+        if dpreds is None:
+            return (None,) * 7
+        ops.scale_inplace(dpreds, g_total.reshape(1).float())
+        return dpreds, None, None, None, None, None, None

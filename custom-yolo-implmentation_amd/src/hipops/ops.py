@@ -1,0 +1,359 @@
+"""Leaf ops: one function = one (or a fixed short chain of) C-ABI call(s) on torch-owned device memory.
+
+Activations are logical (N, C, H, W) tensors whose memory is NHWC ("channels_last"), possibly a channel
+slice of a wider buffer; `geom` extracts (N, C, H, W, ld).  PyTorch is used here only to allocate and
+to carry pointers/streams.  Every function requires CUDA(HIP) tensors -- there is no CPU path.
+"""
+import os
+
+import torch
+
+from . import lib
+
+ALGO = int(os.environ.get("YOLO_HIP_CONV_ALGO", "0"))   # 0 auto, 1 generic VALU kernels, 2 MFMA or error
+
+_DT = {torch.float32: lib.F32, torch.bfloat16: lib.BF16, torch.float16: lib.F16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t}")
+
+
+def _stream(t):
+    if not t.is_cuda:
+        raise RuntimeError("yolo_hip ops need tensors on the GPU: the product path has no CPU fallback "
+                           "(the CPU oracle lives under oracle/ and is test infrastructure)")
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def new_nhwc(n, c, h, w, dtype, device):
+    return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def geom(x):
+    """(N, C, H, W, ld) of an NHWC-in-memory tensor; raises if the memory is not pixel-dense NHWC."""
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    ok = (c == 1 or sc == 1) and (w == 1 or sw == ld) and (h == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld) \
+        and ld >= c
+    if not ok:
+        raise RuntimeError(f"tensor is not NHWC-dense: shape {tuple(x.shape)} strides {x.stride()}")
+    return n, c, h, w, ld
+
+
+def is_nhwc(x):
+    try:
+        geom(x)
+        return True
+    except RuntimeError:
+        return False
+
+
+def to_nhwc(x, dtype):
+    """Any NCHW-shaped tensor -> NHWC memory of `dtype` (tiled transpose kernels); no-op if already so."""
+    if is_nhwc(x):
+        if x.dtype == dtype:
+            return x
+        n, c, h, w, ld = geom(x)          # dtype change of NHWC memory: out through (n, c, m) and back
+        tmp = torch.empty((n, c, h, w), dtype=dtype, device=x.device)
+        lib.call("yolo_nhwc_to_ncm", _p(x), dt(x), ld, _p(tmp), dt(dtype), c * h * w, h * w, 0, n, c, h * w, _stream(x))
+        x = tmp
+    xc = x if x.is_contiguous() else x.contiguous()
+    n, c, h, w = xc.shape
+    out = new_nhwc(n, c, h, w, dtype, x.device)
+    lib.call("yolo_ncm_to_nhwc", _p(xc), dt(xc), c * h * w, h * w, 0, _p(out), dt(dtype), c, n, c, h * w, _stream(xc))
+    return out
+
+
+def head_pack(x, preds, c_off, m_off):
+    """preds[n, c_off:c_off+C, m_off:m_off+H*W] = x (NHWC) -- the (N, no, M) flattening of head.py:119."""
+    n, c, h, w, ld = geom(x)
+    cp, m = preds.shape[1], preds.shape[2]
+    lib.call("yolo_nhwc_to_ncm", _p(x), dt(x), ld, preds.data_ptr() + c_off * m * preds.element_size(), dt(preds),
+             cp * m, m, m_off, n, c, h * w, _stream(x))
+
+
+def head_unpack(dpreds, c_off, c, m_off, h, w):
+    n, cp, m = dpreds.shape
+    out = new_nhwc(n, c, h, w, dpreds.dtype, dpreds.device)
+    lib.call("yolo_ncm_to_nhwc", dpreds.data_ptr() + c_off * m * dpreds.element_size(), dt(dpreds), cp * m, m, m_off,
+             _p(out), dt(out), c, n, c, h * w, _stream(dpreds))
+    return out
+
+
+def copy_channels(src, dst, accumulate=False):
+    n, c, h, w, lds = geom(src)
+    n2, c2, h2, w2, ldd = geom(dst)
+    assert (n, c, h, w) == (n2, c2, h2, w2) and src.dtype == dst.dtype
+    lib.call("yolo_copy_channels", _p(src), lds, _p(dst), ldd, n * h * w, c, int(accumulate), dt(src), _stream(src))
+
+
+def zero_(t):
+    lib.call("yolo_memset0", _p(t), t.numel() * t.element_size(), _stream(t))
+    return t
+
+
+def fill_(t, value):
+    """Small constant vectors (fused-eval path only): plain tensor fill, not on the training path."""
+    return t.fill_(value)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def pack_weights(w, k, stride, mode, dtype):
+    """OIHW parameter -> K-major packed matrix (mode 0 forward, 1 dgrad buffer) in the compute dtype."""
+    o, i = w.shape[0], w.shape[1]
+    w = w if w.is_contiguous() else w.contiguous()
+    if mode == 0:
+        elems = o * lib.query("yolo_conv_kpad", o, i, k, stride, 0, 0)
+    else:
+        elems = lib.query("yolo_conv_dgrad_wbuf_elems", o, i, k, stride)
+    out = torch.empty(elems, dtype=dtype, device=w.device)
+    lib.call("yolo_conv_pack_weights", _p(w), dt(w), o, i, k, stride, mode, _p(out), dt(dtype), _stream(w))
+    return out
+
+
+def conv_out_hw(h, w, k, stride):
+    pad = k // 2
+    return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+
+def conv_fwd(x, wp, bias, cout, k, stride):
+    n, cin, h, w, ldx = geom(x)
+    oh, ow = conv_out_hw(h, w, k, stride)
+    y = new_nhwc(n, cout, oh, ow, x.dtype, x.device)
+    lib.call("yolo_conv2d_fwd", _p(x), ldx, _p(wp), _p(bias), _p(y), cout, n, h, w, cin, oh, ow, cout, k, stride,
+             dt(x), ALGO, _stream(x))
+    return y
+
+
+def conv_dgrad(dy, wb, cin, h, w, k, stride):
+    n, cout, oh, ow, lddy = geom(dy)
+    dx = new_nhwc(n, cin, h, w, dy.dtype, dy.device)
+    lib.call("yolo_conv2d_dgrad", _p(dy), lddy, _p(wb), _p(dx), cin, n, h, w, cin, oh, ow, cout, k, stride, 0,
+             dt(dy), ALGO, _stream(dy))
+    return dx
+
+
+def conv_wgrad(x, dy, k, stride, w_dtype):
+    n, cin, h, w, ldx = geom(x)
+    _, cout, oh, ow, ldy = geom(dy)
+    kpad = lib.query("yolo_conv_kpad", cout, cin, k, stride, 0, 0)
+    dwp = torch.empty(cout * kpad, dtype=torch.float32, device=x.device)
+    lib.call("yolo_conv2d_wgrad", _p(x), ldx, _p(dy), ldy, _p(dwp), n, h, w, cin, oh, ow, cout, k, stride, dt(x),
+             ALGO, _stream(x))
+    dw = torch.empty((cout, cin, k, k), dtype=w_dtype, device=x.device)
+    lib.call("yolo_conv_unpack_wgrad", _p(dwp), cout, cin, k, _p(dw), dt(w_dtype), _stream(x))
+    return dw
+
+
+def dw_fwd(x, w9):
+    n, c, h, w, ldx = geom(x)
+    y = new_nhwc(n, c, h, w, x.dtype, x.device)
+    lib.call("yolo_dwconv3x3_fwd", _p(x), ldx, _p(w9), _p(y), c, n, h, w, c, dt(x), _stream(x))
+    return y
+
+
+def dw_dgrad(dy, w9):
+    n, c, h, w, ld = geom(dy)
+    dx = new_nhwc(n, c, h, w, dy.dtype, dy.device)
+    lib.call("yolo_dwconv3x3_dgrad", _p(dy), ld, _p(w9), _p(dx), c, n, h, w, c, dt(dy), _stream(dy))
+    return dx
+
+
+def dw_wgrad(x, dy):
+    n, c, h, w, ldx = geom(x)
+    _, _, _, _, ldy = geom(dy)
+    dw = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=x.device)
+    lib.call("yolo_dwconv3x3_wgrad", _p(x), ldx, _p(dy), ldy, _p(dw), n, h, w, c, dt(x), _stream(x))
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ BN / act
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def bn_train_stats(y, gamma, beta, running_mean, running_var, momentum, eps):
+    """Batch statistics of y; updates the running buffers in place; -> (mean, invstd, scale, shift)."""
+    n, c, h, w, ld = geom(y)
+    npix = n * h * w
+    nblk = lib.query("yolo_reduce_nblk", npix, c)
+    part = _f32(nblk * 2 * c, y.device)
+    st = _stream(y)
+    lib.call("yolo_bn_stats", _p(y), ld, npix, c, dt(y), _p(part), nblk, st)
+    coef = _f32(4 * c, y.device)
+    mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
+    lib.call("yolo_bn_finalize", _p(part), nblk, npix, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+             float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), st)
+    return mean, invstd, scale, shift
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    c = gamma.numel()
+    coef = _f32(2 * c, gamma.device)
+    lib.call("yolo_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), c,
+             _p(coef[:c]), _p(coef[c:]), _stream(gamma))
+    return coef[:c], coef[c:]
+
+
+def bn_act_fwd(y, scale, shift, act, res=None):
+    n, c, h, w, ld = geom(y)
+    out = new_nhwc(n, c, h, w, y.dtype, y.device)
+    ldr = geom(res)[4] if res is not None else 0
+    lib.call("yolo_bn_act_fwd", _p(y), ld, _p(scale), _p(shift), _p(res), ldr, _p(out), c, n * h * w, c, int(act),
+             dt(y), _stream(y))
+    return out
+
+
+def bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act):
+    """Training-mode backward of act(BN(y)) -> (dy, dgamma, dbeta)."""
+    n, c, h, w, ldy = geom(y)
+    ldd = geom(dout)[4]
+    npix = n * h * w
+    nblk = lib.query("yolo_reduce_nblk", npix, c)
+    part = _f32(nblk * 2 * c, y.device)
+    st = _stream(y)
+    lib.call("yolo_bn_act_bwd_reduce", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), _p(mean), _p(invstd), npix, c,
+             int(act), dt(y), _p(part), nblk, st)
+    buf = _f32(5 * c, y.device)
+    dgamma, dbeta, coef = buf[:c], buf[c:2 * c], buf[2 * c:]
+    lib.call("yolo_bn_bwd_finalize", _p(part), nblk, npix, c, _p(gamma), _p(invstd), _p(dgamma), _p(dbeta), _p(coef), st)
+    dy = new_nhwc(n, c, h, w, y.dtype, y.device)
+    lib.call("yolo_bn_act_bwd_apply", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), _p(mean), _p(invstd), _p(coef),
+             _p(dy), c, npix, c, int(act), dt(y), st)
+    return dy, dgamma, dbeta
+
+
+def bn_act_bwd_eval(dout, y, scale, shift, act):
+    """Backward through act(y*scale+shift) with frozen statistics -> dy."""
+    n, c, h, w, ldy = geom(y)
+    dy = new_nhwc(n, c, h, w, y.dtype, y.device)
+    lib.call("yolo_bn_act_bwd_apply", _p(dout), geom(dout)[4], _p(y), ldy, _p(scale), _p(shift), 0, 0, 0, _p(dy), c,
+             n * h * w, c, int(act), dt(y), _stream(y))
+    return dy
+
+
+def channel_sum(x):
+    n, c, h, w, ld = geom(x)
+    npix = n * h * w
+    nblk = lib.query("yolo_reduce_nblk", npix, c)
+    part = _f32(nblk * 2 * c, x.device)
+    st = _stream(x)
+    lib.call("yolo_bn_stats", _p(x), ld, npix, c, dt(x), _p(part), nblk, st)
+    out = _f32(c, x.device)
+    lib.call("yolo_sum_finalize", _p(part), nblk, c, _p(out), st)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ pool / upsample
+def maxpool5_fwd(x):
+    n, c, h, w, ld = geom(x)
+    out = new_nhwc(n, c, h, w, x.dtype, x.device)
+    idx = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+    lib.call("yolo_maxpool5_fwd", _p(x), ld, _p(out), c, _p(idx), n, h, w, c, dt(x), _stream(x))
+    return out, idx
+
+
+def maxpool5_bwd(dout, idx):
+    n, c, h, w, ld = geom(dout)
+    dx = new_nhwc(n, c, h, w, dout.dtype, dout.device)
+    lib.call("yolo_maxpool5_bwd", _p(dout), ld, _p(idx), _p(dx), c, n, h, w, c, 0, dt(dout), _stream(dout))
+    return dx
+
+
+def upsample2x_fwd(x):
+    n, c, h, w, ld = geom(x)
+    out = new_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
+    lib.call("yolo_upsample2x_fwd", _p(x), ld, _p(out), c, n, h, w, c, dt(x), _stream(x))
+    return out
+
+
+def upsample2x_bwd(dout):
+    n, c, oh, ow, ld = geom(dout)
+    dx = new_nhwc(n, c, oh // 2, ow // 2, dout.dtype, dout.device)
+    lib.call("yolo_upsample2x_bwd", _p(dout), ld, _p(dx), c, n, oh // 2, ow // 2, c, 0, dt(dout), _stream(dout))
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_fwd(qkv, heads, dk, dh, scale):
+    n, cq, h, w, ld = geom(qkv)
+    t = h * w
+    o = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
+    vp = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
+    lse = _f32(n * heads * t, qkv.device)
+    lib.call("yolo_attn_fwd", _p(qkv), ld, _p(o), heads * dh, _p(vp), heads * dh, _p(lse), n, t, heads, dk, dh,
+             float(scale), dt(qkv), _stream(qkv))
+    return o, vp, lse
+
+
+def attn_bwd(qkv, o, d_o, d_vp, lse, heads, dk, dh, scale):
+    n, cq, h, w, ld = geom(qkv)
+    t = h * w
+    dqkv = new_nhwc(n, cq, h, w, qkv.dtype, qkv.device)
+    dbuf = _f32(n * heads * t, qkv.device)
+    lib.call("yolo_attn_bwd", _p(qkv), ld, _p(o), geom(o)[4], _p(d_o), geom(d_o)[4], _p(d_vp),
+             geom(d_vp)[4] if d_vp is not None else 0, _p(lse), _p(dbuf), _p(dqkv), cq, n, t, heads, dk, dh,
+             float(scale), dt(qkv), _stream(qkv))
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ loss / post
+def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_dfl, lambda_cls, want_grad):
+    """-> (out[3] fp32 = total, mean_dfl, mean_cls ; dpreds or None)."""
+    n, cp, a = preds.shape
+    assert preds.is_contiguous() and cp == 64 + nc
+    anchors = anchors.to(preds.dtype).contiguous()
+    strides = strides.to(preds.dtype).contiguous()
+    ws = torch.empty(lib.query("yolo_loss_workspace_bytes", n, a, n_gt), dtype=torch.uint8, device=preds.device)
+    out = _f32(3, preds.device)
+    dpreds = torch.empty_like(preds) if want_grad else None
+    lib.call("yolo_loss_dfl_qfl", _p(preds), _p(anchors), _p(strides), dt(preds), n, nc, a, _p(gt), _p(gt_off),
+             _p(gt_img), n_gt, float(lambda_dfl), float(lambda_cls), _p(dpreds), _p(out), _p(ws), _stream(preds))
+    return out, dpreds, ws
+
+
+def scale_inplace(x, scale_dev):
+    lib.call("yolo_scale_inplace", _p(x), x.numel(), dt(x), _p(scale_dev), _stream(x))
+    return x
+
+
+def head_decode(preds, anchors, strides, nc):
+    n, cp, a = preds.shape
+    preds = preds.contiguous()
+    y = torch.empty((n, 4 + nc, a), dtype=preds.dtype, device=preds.device)
+    lib.call("yolo_head_decode", _p(preds), _p(anchors.to(preds.dtype).contiguous()),
+             _p(strides.to(preds.dtype).contiguous()), _p(y), n, nc, a, dt(preds), _stream(preds))
+    return y
+
+
+def dfl_expect(x):
+    b, c, a = x.shape
+    x = x.contiguous()
+    y = torch.empty((b, 4, a), dtype=x.dtype, device=x.device)
+    lib.call("yolo_dfl_expect", _p(x), _p(y), b, a, dt(x), _stream(x))
+    return y
+
+
+def nms(y, nc, conf_thres, iou_thres, classes, agnostic, multi_label, max_det):
+    """-> (rows fp32 [bs][max_det][6], counts int32 [bs], status int32 [1])."""
+    import ctypes
+    bs, _, m = y.shape
+    y = y.contiguous()
+    ws = torch.empty(lib.query("yolo_nms_workspace_bytes", bs, m, nc, int(multi_label)), dtype=torch.uint8, device=y.device)
+    rows = zero_(torch.empty((bs, max_det, 6), dtype=torch.float32, device=y.device))
+    counts = zero_(torch.empty(bs, dtype=torch.int32, device=y.device))
+    status = zero_(torch.empty(1, dtype=torch.int32, device=y.device))
+    cl = list(classes) if classes is not None else []
+    arr = (ctypes.c_int * max(1, len(cl)))(*cl)
+    lib.call("yolo_nms", _p(y), dt(y), bs, nc, m, float(conf_thres), float(iou_thres), ctypes.cast(arr, ctypes.c_void_p),
+             len(cl), int(agnostic), int(multi_label), int(max_det), _p(rows), _p(counts), _p(status), _p(ws), _stream(y))
+    return rows, counts, status

@@ -1,0 +1,58 @@
+"""Detection head: per level a box branch (3x3, 3x3, 1x1 -> 4*16 DFL logits) and a class branch
+(dw3x3, 1x1, dw3x3, 1x1, 1x1 -> nc logits); outputs are written transposed straight into the
+(N, 64+nc, M) prediction tensor.  Mirrors the reference's src/model/head.py:35-121."""
+import math
+from typing import List
+
+import torch
+from torch import nn
+
+from src.hipops import functions as F_
+from src.model.model_blocks import DFL, Conv
+from src.utils.model_utils import make_anchors_cached
+
+
+class Head(nn.Module):
+    anchors = torch.empty(0)
+    strides = torch.empty(0)
+
+    def __init__(self, nc: int = 1, filters: List[int] = []):
+        super().__init__()
+        self.ch = 16
+        self.nc = nc
+        self.nl = len(filters)
+        self.no = nc + self.ch * 4
+        self.stride = torch.zeros(self.nl)
+        box = max(64, filters[0] // 4)
+        cls = max(80, filters[0], self.nc)
+        self.dfl = DFL(self.ch)
+        self.box = nn.ModuleList(
+            nn.Sequential(Conv(x, box, nn.SiLU(), k=3, p=1), Conv(box, box, nn.SiLU(), k=3, p=1),
+                          nn.Conv2d(box, out_channels=4 * self.ch, kernel_size=1)) for x in filters)
+        self.cls = nn.ModuleList(
+            nn.Sequential(Conv(x, x, nn.SiLU(), k=3, p=1, g=x), Conv(x, cls, nn.SiLU()),
+                          Conv(cls, cls, nn.SiLU(), k=3, p=1, g=cls), Conv(cls, cls, nn.SiLU()),
+                          nn.Conv2d(cls, out_channels=self.nc, kernel_size=1)) for x in filters)
+        self.initialize_biases()
+
+    def initialize_biases(self):
+        """Class-logit bias = log(p/(1-p)) with p = 0.01 (reference :66-74)."""
+        b = math.log(1e-2 / (1 - 1e-2))
+        for branch in self.cls:
+            nn.init.constant_(branch[-1].bias, b)
+
+    @staticmethod
+    def _branch(seq, x):
+        for m in seq[:-1]:
+            x = m(x)
+        last = seq[-1]
+        return F_.ConvBias.apply(x, last.weight, last.bias, 1, 1)
+
+    def forward(self, x):
+        outs = []
+        for i in range(self.nl):
+            outs += [self._branch(self.box[i], x[i]), self._branch(self.cls[i], x[i])]
+        preds = F_.HeadPack.apply(*outs)
+        shapes = tuple((int(o.shape[2]), int(o.shape[3])) for o in outs[::2])
+        anchors, strides = make_anchors_cached(shapes, tuple(float(s) for s in self.stride), preds.dtype, preds.device)
+        return preds, anchors, strides

@@ -1,0 +1,104 @@
+"""YoloDFLQFLoss with the reference's constructor and call signature (src/model/losses.py:84-93,277-281),
+computed by one fused HIP pass (yolo_loss_dfl_qfl: value + d/dpreds) instead of ~25 elementwise ATen
+kernels plus a Python loop of ~100 tiny ops per image.  Reference semantics kept on purpose:
+plain-IoU soft target with the b1_y2 = h + cy/2 slip (:20), nearest predicted-centre assignment via the
+cdist formula (:214-215), last-GT-wins on duplicate anchors (:261) with the IoU gradient still reaching
+every GT, lambda_box accepted and unused (:275), DFL targets clamped to [0, 14.99] (:246)."""
+import torch
+import torch.nn as nn
+
+from src.hipops import functions as F_
+
+
+class PackedTargets:
+    """GT boxes of a batch flattened for the kernel: gt (G,5) fp32, offsets (N+1) int32, image id (G) int32."""
+
+    def __init__(self, gt_boxes_list, device):
+        counts = [int(g.shape[0]) if g.numel() > 0 else 0 for g in gt_boxes_list]
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        self.n_gt = offs[-1]
+        self.n_img = len(counts)
+        live = [g.reshape(-1, 5).to(device=device, dtype=torch.float32) for g, c in zip(gt_boxes_list, counts) if c]
+        self.gt = torch.cat(live).contiguous() if live else torch.zeros((1, 5), dtype=torch.float32, device=device)
+        img = [i for i, c in enumerate(counts) for _ in range(c)] or [0]
+        self.gt_off = torch.tensor(offs, dtype=torch.int32).to(device, non_blocking=True)
+        self.gt_img = torch.tensor(img, dtype=torch.int32).to(device, non_blocking=True)
+
+    def as_tuple(self):
+        return self.gt, self.gt_off, self.gt_img, self.n_gt
+
+
+class LazyLossDict(dict):
+    """{"total_loss","box_loss","cls_loss": float}.  The three scalars stay on the device until first
+    read and then arrive with ONE device->host copy (the reference does three .item() syncs, :278-280)."""
+
+    _KEYS = ("total_loss", "box_loss", "cls_loss")
+
+    def __init__(self, scalars):
+        super().__init__()
+        self._scalars = scalars
+
+    def _fill(self):
+        if self._scalars is not None:
+            vals = self._scalars.tolist()
+            self._scalars = None
+            for k, v in zip(self._KEYS, vals):
+                dict.__setitem__(self, k, v)
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._fill()
+        return dict.get(self, k, default)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return 3
+
+    def __contains__(self, k):
+        return k in self._KEYS
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+
+class YoloDFLQFLoss(nn.Module):
+    def __init__(self, num_classes=171, lambda_box=1.5, lambda_cls=1.0, lambda_dfl=1.5, reg_max=16):
+        super().__init__()
+        if reg_max != 16:
+            raise ValueError("the loss kernel is built for reg_max = 16 (the head's DFL width)")
+        self.num_classes = num_classes
+        self.lambda_box = lambda_box      # accepted, unused -- as in the reference
+        self.lambda_cls = lambda_cls
+        self.lambda_dfl = lambda_dfl
+        self.reg_max = reg_max
+
+    def forward(self, preds, gt_boxes_list, anchors, strides):
+        """preds (N, 64+nc, M); gt_boxes_list: N tensors (Mi,5) [cx,cy,w,h,cls] in pixels, or a
+        PackedTargets; anchors (2,M); strides (1,M) -> (loss 0-d tensor with grad, dict of 3 floats)."""
+        packed = gt_boxes_list if isinstance(gt_boxes_list, PackedTargets) else PackedTargets(gt_boxes_list, preds.device)
+        if packed.n_img != preds.shape[0]:
+            raise ValueError("one GT tensor per image is required")
+        total, scalars = F_.DflQflLoss.apply(preds, anchors, strides, packed.as_tuple(), self.num_classes,
+                                             float(self.lambda_dfl), float(self.lambda_cls))
+        return total, LazyLossDict(scalars)

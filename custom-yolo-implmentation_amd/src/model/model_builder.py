@@ -1,0 +1,69 @@
+"""Model = Backbone + Neck + Head with the reference's API (src/model/model_builder.py:13-139):
+forward(x) -> (preds[N,64+nc,M], anchors[2,M], strides[1,M]); fuse(); load_weights(); inference()."""
+from typing import List
+
+import torch
+from torch import nn
+
+from src.hipops import ops
+from src.model.backbone import Backbone
+from src.model.head import Head
+from src.model.model_blocks import Conv
+from src.model.neck import Neck
+from src.utils.model_utils import fuse_conv, non_max_suppression
+
+
+class Model(nn.Module):
+    def __init__(self, width: List[int], depth: List[int], csp: List[bool], num_classes: int):
+        super().__init__()
+        self.net = Backbone(width, depth, csp)
+        self.fpn = Neck(width, depth, csp)
+        self.num_classes = num_classes
+        self.head = Head(num_classes, (width[3], width[4], width[5]))
+        # The reference measures the strides with a 640x640 CPU dummy pass (:37-45); they are fixed by
+        # the architecture (three / four / five stride-2 stages), so no pass is needed here.
+        self.head.stride = torch.tensor([8.0, 16.0, 32.0])
+        self.stride = self.head.stride
+
+    def forward(self, x):
+        return self.head(list(self.fpn(self.net(x))))
+
+    def fuse(self):
+        """Fold every Conv's BatchNorm into its conv (inference only), reference :52-58."""
+        for m in self.modules():
+            if type(m) is Conv and hasattr(m, "norm"):
+                m.conv = fuse_conv(m.conv, m.norm)
+                m.forward = m.fuse_forward
+                delattr(m, "norm")
+        return self
+
+    def load_weights(self, weights_path):
+        checkpoint = torch.load(weights_path, map_location=next(self.parameters()).device)
+        state = checkpoint["model_state"] if isinstance(checkpoint, dict) and "model_state" in checkpoint else checkpoint
+        self.load_state_dict(state)
+        print(f"Weights loaded successfully from {weights_path}")
+
+    def inference(self, image, conf_thres=0.25, iou_thres=0.45):
+        """Detections [x1,y1,x2,y2,conf,cls] per image; class scores are the raw logits, as in the
+        reference (:115-139).  Decode (DFL expectation -> xywh -> *stride) is one fused kernel."""
+        self.eval()
+        if isinstance(image, str):
+            from PIL import Image
+            image = Image.open(image).convert("RGB")
+        if not isinstance(image, torch.Tensor):
+            try:
+                from PIL import Image
+                is_pil = isinstance(image, Image.Image)
+            except ImportError:
+                is_pil = False
+            if not is_pil:
+                raise ValueError("Unsupported image type. Must be path, PIL Image, or Tensor.")
+            from src.data.transforms import get_val_transforms
+            image = get_val_transforms()(image)
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
+        image = image.to(next(self.parameters()).device)
+        with torch.no_grad():
+            preds, anchors, strides = self.forward(image)
+            y = ops.head_decode(preds, anchors, strides, self.head.nc)
+            return non_max_suppression(y, conf_thres=conf_thres, iou_thres=iou_thres, nc=self.num_classes)

@@ -1,0 +1,96 @@
+/* libyolo_hip.so -- C ABI of the MI355X (gfx950) YOLO training hot path.
+ *
+ * The reference (DarylFernandes99/custom-yolo-implmentation) has no FFI: its hot path is stock
+ * PyTorch ops called from src/model/*.py.  Each entry point below replaces the ATen/torchvision op
+ * the reference reaches at the cited file:line; the host mirror under
+ * custom-yolo-implmentation_amd/src/ binds them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (sole exception: yolo_nms' `classes`, a host array of <=32 ints
+ *     copied into the kernel arguments); nothing here allocates, frees or synchronises
+ *   - activations are NHWC: element (pixel p, channel c) at base[p*ld + c], ld >= C (channel slices of
+ *     concat buffers are passed as base+offset with the buffer's ld); dtype codes below; parameters,
+ *     statistics and reductions are fp32
+ *   - return 0 on success, a hipError_t value or YOLO_ERR_* otherwise; never aborts
+ *   - re-entrant, no global mutable state; the caller's stream is explicit (autograd's backward thread
+ *     and DDP hooks call in concurrently with the main thread)
+ *
+ * One prototype per line, `int|long|size_t name(args);` -- the Python loader parses this file.
+ */
+#ifndef YOLO_HIP_H
+#define YOLO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define YOLO_F32 0
+#define YOLO_BF16 1
+#define YOLO_F16 2
+#define YOLO_ERR_ARG 1001
+#define YOLO_ERR_DTYPE 1002
+#define YOLO_ACT_IDENTITY 0
+#define YOLO_ACT_SILU 1
+
+/* ---- layout / copies (replace .view/.transpose/torch.cat/.chunk copies: head.py:87,119, model_blocks.py:92,123-125,156,249-252, neck.py:41-44) */
+int yolo_memset0(void* p, size_t bytes, hipStream_t st);
+int yolo_ncm_to_nhwc(const void* src, int src_dtype, long sn, long sc, long off, void* dst, int dst_dtype, int ld, int N, int C, int HW, hipStream_t st);
+int yolo_nhwc_to_ncm(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, long sn, long sc, long off, int N, int C, int HW, hipStream_t st);
+int yolo_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, long npix, int C, int accumulate, int dtype, hipStream_t st);
+int yolo_scale_inplace(void* x, long n, int dtype, const float* scale_dev, hipStream_t st);
+
+/* ---- convolution (nn.Conv2d: model_blocks.py:27, head.py:50,60; its autograd dgrad/wgrad) */
+int yolo_conv_kpad(int O, int I, int k, int stride, int mode, int cls);
+long yolo_conv_dgrad_wbuf_elems(int O, int I, int k, int stride);
+int yolo_conv_pack_weights(const void* w_oihw, int w_dtype, int O, int I, int k, int stride, int mode, void* out, int out_dtype, hipStream_t st);
+int yolo_conv_unpack_wgrad(const float* dwp, int O, int I, int k, void* dw_oihw, int dw_dtype, hipStream_t st);
+int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
+int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
+int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dwp, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
+/* depthwise 3x3 (groups == channels: model_blocks.py:183, head.py:56,58) */
+int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype, hipStream_t st);
+int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int dtype, hipStream_t st);
+int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, int N, int H, int W, int C, int dtype, hipStream_t st);
+
+/* ---- BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU/Identity + residual add (model_blocks.py:28-34,62,223-224) */
+int yolo_reduce_nblk(long npix, int C);
+int yolo_bn_stats(const void* y, int ldy, long npix, int C, int dtype, float* partial, int nblk, hipStream_t st);
+int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
+int yolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C, float* scale, float* shift, hipStream_t st);
+int yolo_sum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st);
+int yolo_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype, hipStream_t st);
+int yolo_bn_act_bwd_reduce(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* partial, int nblk, hipStream_t st);
+int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st);
+int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, const float* coef, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
+
+/* ---- SPPF max pool (model_blocks.py:150-156) and nearest x2 upsample (neck.py:31,41-42) */
+int yolo_maxpool5_fwd(const void* x, int ldx, void* out, int ldo, uint8_t* idx, int N, int H, int W, int C, int dtype, hipStream_t st);
+int yolo_maxpool5_bwd(const void* dout, int ldd, const uint8_t* idx, void* dx, int ldx, int N, int H, int W, int C, int accumulate, int dtype, hipStream_t st);
+int yolo_upsample2x_fwd(const void* x, int ldx, void* out, int ldo, int N, int H, int W, int C, int dtype, hipStream_t st);
+int yolo_upsample2x_bwd(const void* dout, int ldd, void* dx, int ldx, int N, int H, int W, int C, int accumulate, int dtype, hipStream_t st);
+
+/* ---- PSA attention core (model_blocks.py:186-197) */
+int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, float* lse, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
+int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv, const float* lse, float* Dbuf, void* dqkv, int lddq, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
+
+/* ---- YoloDFLQFLoss forward+gradient (losses.py:93-281) */
+size_t yolo_loss_workspace_bytes(int N, int A, int G);
+int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A, const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl, float lambda_cls, void* dpreds, float* out, void* workspace, hipStream_t st);
+
+/* ---- inference decode (model_builder.py:123-136) and class-aware NMS (model_utils.py:174-279, torchvision.ops.nms) */
+int yolo_head_decode(const void* preds, const void* anchors, const void* strides, void* y, int N, int nc, int A, int dtype, hipStream_t st);
+int yolo_dfl_expect(const void* x, void* y, int B, int A, int dtype, hipStream_t st);
+int yolo_nms_capacity(int M, int nc, int multi_label);
+size_t yolo_nms_workspace_bytes(int bs, int M, int nc, int multi_label);
+int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, float iou_thres, const int* classes, int n_classes, int agnostic, int multi_label, int max_det, float* out, int* out_count, int* status, void* workspace, hipStream_t st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
