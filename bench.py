@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of full training steps (fwd + DFL/QFL loss + bwd + grad sync + AdamW) of the
+`s` preset at 640x640 bf16 on synthetic COCO-shaped batches, 32 images per GPU (BASELINE.json configs[1]/[2]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = all ranks' images / max-over-ranks time of exactly K steps with the
+inputs resident in HBM.  `roofline` = the dominant kernel group of the step measured live with stream events
+in an instrumented (eager) step: algorithmic FLOPs of those launches / their summed duration vs the dense bf16
+MFMA peak.  `cpu_baseline` (rank 0, N=1 only) = the CPU oracle restatement timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "custom-yolo-implmentation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PRESET_S = dict(csp=[False, True], depth=[1] * 6, width=[3, 32, 64, 128, 256, 512])
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(n, res, nc, seed, device):
+    """randn images; per image 1..20 boxes (cx,cy,w,h,cls) in pixels -- the collate_fn format."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(n, 3, res, res, generator=g)
+    gts = []
+    for _ in range(n):
+        m = int(torch.randint(1, 21, (1,), generator=g))
+        gts.append(torch.cat([torch.rand(m, 2, generator=g) * res, torch.rand(m, 2, generator=g) * (0.4 * res) + 8,
+                              torch.randint(0, nc, (m, 1), generator=g).float()], 1))
+    return img.to(device), [t.to(device) for t in gts]
+
+
+class KernelTimer:
+    """Brackets selected leaf ops with events on torch's current stream (the stream the kernels launch on)."""
+
+    def __init__(self, ops):
+        self.ops, self.rec, self.saved = ops, [], {}
+
+    def _wrap(self, name, group, flops_fn, bytes_fn):
+        fn = getattr(self.ops, name)
+        self.saved[name] = fn
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.rec.append((group, e0, e1, flops_fn(out, *a) if flops_fn else 0.0, bytes_fn(out, *a) if bytes_fn else 0.0))
+            return out
+        setattr(self.ops, name, timed)
+
+    def install(self):
+        def conv_flops(out, x, wp, bias, cout, k, stride):
+            n, _, oh, ow = out.shape
+            return 2.0 * n * oh * ow * cout * x.shape[1] * k * k
+
+        def dgrad_flops(out, dy, wb, cin, h, w, k, stride):
+            n, cout, oh, ow = dy.shape
+            return 2.0 * n * oh * ow * cout * cin * k * k
+
+        def wgrad_flops(out, x, dy, k, stride, wd):
+            n, cout, oh, ow = dy.shape
+            return 2.0 * n * oh * ow * cout * x.shape[1] * k * k
+
+        def io_bytes(out, *a):
+            tot = 0
+            outs = (out,) if isinstance(out, torch.Tensor) else tuple(out or ())
+            for t in a + outs:
+                if isinstance(t, torch.Tensor) and t.dim() == 4:
+                    tot += t.numel() * t.element_size()
+            return float(tot)
+
+        self._wrap("conv_fwd", "conv_mfma(fwd+dgrad)", conv_flops, io_bytes)
+        self._wrap("conv_dgrad", "conv_mfma(fwd+dgrad)", dgrad_flops, io_bytes)
+        self._wrap("conv_wgrad", "wgrad_mfma", wgrad_flops, io_bytes)
+        for nm in ("bn_train_stats", "bn_act_fwd", "bn_act_bwd", "copy_channels", "dw_fwd", "dw_dgrad", "dw_wgrad",
+                   "maxpool5_fwd", "maxpool5_bwd", "upsample2x_fwd", "upsample2x_bwd", "head_pack", "head_unpack"):
+            self._wrap(nm, "elementwise(bn/act/copy/pool)", None, io_bytes)
+        self._wrap("attn_fwd", "attention", None, io_bytes)
+        self._wrap("attn_bwd", "attention", None, io_bytes)
+        self._wrap("loss_fwd_bwd", "loss", None, None)
+        return self
+
+    def remove(self):
+        for k, v in self.saved.items():
+            setattr(self.ops, k, v)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        groups = {}
+        for grp, e0, e1, fl, by in self.rec:
+            g = groups.setdefault(grp, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            g["ms"] += e0.elapsed_time(e1)
+            g["launches"] += 1
+            g["flops"] += fl
+            g["bytes"] += by
+        return groups
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE config 2/3: 32)")
+    ap.add_argument("--res", type=int, default=640)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+
+    from src.hipops import ops
+    from src.model.losses import PackedTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.graph_step import TrainStepRunner
+
+    nc = 80
+    torch.manual_seed(0)                      # identical initial weights on every rank (DDP broadcasts rank 0's)
+    model = Model(**PRESET_S, num_classes=nc).to(dev).train()
+    if world > 1:
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    crit = YoloDFLQFLoss(num_classes=nc, lambda_box=1.5, lambda_cls=1.0)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
+    img, gts = synthetic_batch(args.batch, args.res, nc, 1234 + rank, dev)
+    packed = PackedTargets(gts, dev)
+    runner = TrainStepRunner(model, crit, opt, "bfloat16", use_graph=not args.no_graph,
+                             grad_comm_dtype=torch.bfloat16 if world > 1 else None)
+    runner.capture(img, packed)
+
+    for _ in range(args.warmup):
+        runner.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    final_loss = float(loss)
+    if rank == 0:
+        print(f"[bench] {args.steps} steps in {dt:.4f} s -> {args.batch * world * args.steps / dt:.1f} img/s", file=sys.stderr, flush=True)
+
+    roofline, groups_out = None, None
+    if rank == 0 and not args.no_roofline:
+        timer = KernelTimer(ops).install()
+        try:
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(1.5e9))            # park the GPU so the host queues the whole step ahead:
+            #                                          event pairs then bracket kernel time, not launch latency
+            runner._eager_step(img, packed)          # one instrumented eager step (same kernels, same shapes)
+            groups = timer.summary()
+        finally:
+            timer.remove()
+        groups_out = {k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                              tflops=round(v["flops"] / v["ms"] / 1e9, 1) if v["flops"] else None,
+                              gbs=round(v["bytes"] / v["ms"] / 1e6, 1) if v["bytes"] else None) for k, v in groups.items()}
+        dom = max((k for k in groups if groups[k]["flops"] > 0), key=lambda k: groups[k]["ms"])
+        g = groups[dom]
+        ach = g["flops"] / g["ms"] / 1e9
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, launches=g["launches"],
+                        avg_launch_us=round(1e3 * g["ms"] / g["launches"], 2),
+                        algorithmic_gflop_per_launch=round(g["flops"] / g["launches"] / 1e9, 3))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.train_step import time_cpu_steps
+        cpu = time_cpu_steps("s", args.res, batch=2, steps=8, warmup=1, budget_s=25.0)
+        cpu["value"] = round(cpu["value"], 3)
+
+    if rank == 0:
+        gb = args.batch * world
+        out = dict(metric="images/sec (640x640 bf16)", value=round(gb * args.steps / dt, 2), unit="images/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+                   config=dict(workload=f"preset s (width 32..512, depth 1) {args.res}x{args.res} train step "
+                                        f"(fwd+DFL/QFL loss+bwd+grad sync+AdamW), COCO-80 synthetic, {args.batch} img/GPU",
+                               global_batch=gb, parallelism=f"dp{world}", hip_graph=runner.graph is not None,
+                               optimizer_in_graph=runner.opt_in_graph, final_loss=round(final_loss, 5)),
+                   roofline=roofline, roofline_groups=groups_out, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_candidates(const T* __restrict__ y, int
     const int img = blockIdx.x;
     const T* yi = y + (long)img * (4 + nc) * M;
     float* out = rows + (long)img * cap * 6;
+    conf_thres = rt<T>(conf_thres);      // torch compares a T tensor with the Python scalar cast to T
     int base = 0;
     for (int m0 = 0; m0 < M; m0 += 256) {
         const int m = m0 + threadIdx.x;

@@ -4,6 +4,9 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- must come first: libyolo_hip.so has to bind to the HIP runtime PyTorch loaded,
+#                       or its launches would go through a second runtime that does not know torch's streams
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libyolo_hip.so")
 HEADER_PATHS = [os.path.join(_HERE, "..", "..", "..", "include", "yolo_hip.h"),

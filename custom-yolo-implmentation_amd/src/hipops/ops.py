@@ -330,8 +330,11 @@ def head_decode(preds, anchors, strides, nc):
     n, cp, a = preds.shape
     preds = preds.contiguous()
     y = torch.empty((n, 4 + nc, a), dtype=preds.dtype, device=preds.device)
-    lib.call("yolo_head_decode", _p(preds), _p(anchors.to(preds.dtype).contiguous()),
-             _p(strides.to(preds.dtype).contiguous()), _p(y), n, nc, a, dt(preds), _stream(preds))
+    # keep the converted copies alive in locals: a temporary freed before the launch may be handed to the
+    # next allocation and overwritten
+    anc = anchors.to(preds.dtype).contiguous()
+    strd = strides.to(preds.dtype).contiguous()
+    lib.call("yolo_head_decode", _p(preds), _p(anc), _p(strd), _p(y), n, nc, a, dt(preds), _stream(preds))
     return y
 
 

@@ -1,0 +1,311 @@
+"""-m gpu: every HIP leaf (C-ABI entry point) against its plain-torch stand-in on the same seeded inputs.
+
+Tolerances: fp32 kernels 1e-4 relative to the tensor's max magnitude; bf16/f16 kernels accumulate in fp32
+and round once, the stand-in does the same from the same rounded inputs, so 2 output ulps
+(bf16: 2^-7, f16: 2^-10 relative) of the tensor's max magnitude.  Integer outputs (pool argmax,
+assignment, NMS rows) exact."""
+import pytest
+import torch
+
+import emulated_ops as emu
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2.0 ** -6, torch.float16: 2.0 ** -9}
+
+
+def ops():
+    from src.hipops import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def nhwc(t, pad_c=0):
+    """CPU NHWC tensor, optionally as a channel slice of a wider buffer (ld = C + pad_c)."""
+    o = ops()
+    n, c, h, w = t.shape
+    buf = o.new_nhwc(n, c + pad_c, h, w, t.dtype, "cpu")
+    if pad_c:
+        buf.fill_(7.0)
+    view = buf[:, pad_c // 2:pad_c // 2 + c]
+    view.copy_(t)
+    return view
+
+
+def dev(t, pad_c=0):
+    """Same memory layout on the GPU (keeps the slice/ld structure)."""
+    if t is None:
+        return None
+    if t.dim() != 4 or not ops().is_nhwc(t):
+        return t.to(DEV)
+    o = ops()
+    n, c, h, w = t.shape
+    ld = o.geom(t)[4]
+    buf = o.new_nhwc(n, ld, h, w, t.dtype, DEV)
+    off = (ld - c) // 2 if ld > c else 0
+    buf.fill_(7.0)
+    view = buf[:, off:off + c]
+    view.copy_(t.to(DEV))
+    return view
+
+
+def check(got, want, dtype, what, scale=None, mult=1.0):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    ref = float(want.abs().max()) if scale is None else scale
+    err = float((got - want).abs().max())
+    lim = TOL[dtype] * mult * max(ref, 1e-6)
+    assert err <= lim, f"{what}: max abs err {err:.4e} > {lim:.4e} (ref max {ref:.3e})"
+
+
+# ------------------------------------------------------------------------------------------ layout / copies
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_to_nhwc_and_head_pack_roundtrip(dtype):
+    o = ops()
+    x = rnd(2, 37, 9, 11, seed=1)
+    y = o.to_nhwc(x.to(DEV), dtype)
+    assert o.is_nhwc(y) and y.dtype == dtype
+    check(y, x.to(dtype), dtype, "to_nhwc")
+    preds = torch.full((2, 50, 150), -3.0, dtype=dtype, device=DEV)
+    o.head_pack(y, preds, 5, 20)
+    want = torch.full((2, 50, 150), -3.0).to(dtype)
+    emu.head_pack(x.to(dtype), want, 5, 20)
+    assert torch.equal(preds.cpu(), want)
+    back = o.head_unpack(preds, 5, 37, 20, 9, 11)
+    assert torch.equal(back.cpu(), x.to(dtype))
+
+
+@pytest.mark.parametrize("dtype,c,pad", [(torch.float32, 12, 4), (torch.bfloat16, 16, 16), (torch.bfloat16, 6, 3)])
+def test_copy_channels(dtype, c, pad):
+    o = ops()
+    src, dst = nhwc(rnd(2, c, 5, 7, seed=2).to(dtype), pad), nhwc(rnd(2, c, 5, 7, seed=3).to(dtype), pad)
+    for acc in (False, True):
+        d_gpu, d_cpu = dev(dst), dst.clone()
+        o.copy_channels(dev(src), d_gpu, acc)
+        emu.copy_channels(src, d_cpu, acc)
+        check(d_gpu, d_cpu, dtype, f"copy_channels acc={acc}")
+
+
+# ------------------------------------------------------------------------------------------ convolution
+CONV_CASES = [  # cin, cout, h, w, k, s, pad_c
+    (3, 16, 17, 19, 3, 2, 0), (16, 32, 12, 12, 1, 1, 0), (16, 16, 13, 11, 3, 1, 16), (32, 64, 16, 16, 3, 2, 0),
+    (64, 128, 9, 9, 3, 1, 0), (96, 24, 10, 10, 1, 1, 32), (8, 8, 6, 6, 3, 1, 0), (48, 40, 7, 9, 3, 2, 0),
+    (128, 256, 8, 8, 1, 1, 0),
+]
+CONV_MODES = [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1), (torch.float16, 0)]
+
+
+@pytest.mark.parametrize("dtype,algo", CONV_MODES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype, algo, monkeypatch):
+    o = ops()
+    monkeypatch.setattr(o, "ALGO", algo)
+    cin, cout, h, w, k, s, pad_c = case
+    n = 3
+    x = nhwc(rnd(n, cin, h, w, seed=10).to(dtype), pad_c)
+    wt = rnd(cout, cin, k, k, seed=11, scale=(cin * k * k) ** -0.5)
+    bias = rnd(cout, seed=12)
+    # forward (+bias)
+    y_ref = emu.conv_fwd(x, emu.pack_weights(wt, k, s, 0, dtype), bias, cout, k, s)
+    y = o.conv_fwd(dev(x), o.pack_weights(wt.to(DEV), k, s, 0, dtype), bias.to(DEV), cout, k, s)
+    check(y, y_ref, dtype, "conv_fwd")
+    # dgrad
+    oh, ow = y_ref.shape[2:]
+    dy = nhwc(rnd(n, cout, oh, ow, seed=13).to(dtype), pad_c)
+    if cin >= 8:
+        dx_ref = emu.conv_dgrad(dy, emu.pack_weights(wt, k, s, 1, dtype), cin, h, w, k, s)
+        dx = o.conv_dgrad(dev(dy), o.pack_weights(wt.to(DEV), k, s, 1, dtype), cin, h, w, k, s)
+        check(dx, dx_ref, dtype, "conv_dgrad")
+    # wgrad (fp32 accumulation over n*oh*ow products; atomics => order noise)
+    dw_ref = emu.conv_wgrad(x, dy, k, s, torch.float32)
+    dw = o.conv_wgrad(dev(x), dev(dy), k, s, torch.float32)
+    check(dw, dw_ref, torch.float32, "conv_wgrad", mult=4.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,h,w", [(16, 12, 12), (24, 7, 9), (128, 10, 10)])
+def test_depthwise(dtype, c, h, w):
+    o = ops()
+    x, dy = nhwc(rnd(2, c, h, w, seed=20).to(dtype)), nhwc(rnd(2, c, h, w, seed=21).to(dtype), 8)
+    w9 = rnd(c, 9, seed=22, scale=0.3)
+    check(o.dw_fwd(dev(x), w9.to(DEV)), emu.dw_fwd(x, w9), dtype, "dw_fwd")
+    check(o.dw_dgrad(dev(dy), w9.to(DEV)), emu.dw_dgrad(dy, w9), dtype, "dw_dgrad")
+    check(o.dw_wgrad(dev(x), dev(dy)), emu.dw_wgrad(x, dy), torch.float32, "dw_wgrad", mult=4.0)
+
+
+# ------------------------------------------------------------------------------------------ BN + act
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,act,pad", [(16, 1, 0), (24, 0, 8), (96, 1, 0), (6, 1, 0)])
+def test_bn_act_train_fwd_bwd(dtype, c, act, pad):
+    o = ops()
+    n, h, w = 3, 11, 13
+    y = nhwc((rnd(n, c, h, w, seed=30) * 1.5 + 0.3).to(dtype), pad)
+    res = nhwc(rnd(n, c, h, w, seed=31).to(dtype))
+    gamma, beta = 1 + 0.1 * rnd(c, seed=32), 0.1 * rnd(c, seed=33)
+    rm, rv = 0.1 * rnd(c, seed=34), 1 + 0.1 * rnd(c, seed=35).abs()
+    rm_g, rv_g = rm.clone().to(DEV), rv.clone().to(DEV)
+    ref = emu.bn_train_stats(y, gamma, beta, rm, rv, 0.03, 1e-3)
+    got = o.bn_train_stats(dev(y), gamma.to(DEV), beta.to(DEV), rm_g, rv_g, 0.03, 1e-3)
+    for g, r, nm in zip(got, ref, ("mean", "invstd", "scale", "shift")):
+        check(g, r, torch.float32, nm, mult=2.0)
+    check(rm_g, rm, torch.float32, "running_mean"), check(rv_g, rv, torch.float32, "running_var")
+    out_ref = emu.bn_act_fwd(y, ref[2], ref[3], act, res)
+    out = o.bn_act_fwd(dev(y), got[2], got[3], act, dev(res))
+    check(out, out_ref, dtype, "bn_act_fwd")
+    dout = nhwc(rnd(n, c, h, w, seed=36).to(dtype), pad)
+    dy_ref, dg_ref, db_ref = emu.bn_act_bwd(dout, y, ref[2], ref[3], ref[0], ref[1], gamma, act)
+    dy, dg, db = o.bn_act_bwd(dev(dout), dev(y), got[2], got[3], got[0], got[1], gamma.to(DEV), act)
+    check(dy, dy_ref, dtype, "bn_bwd dy", mult=2.0)
+    check(dg, dg_ref, torch.float32, "dgamma", mult=10.0), check(db, db_ref, torch.float32, "dbeta", mult=10.0)
+    check(o.bn_act_bwd_eval(dev(dout), dev(y), got[2], got[3], act), emu.bn_act_bwd_eval(dout, y, ref[2], ref[3], act),
+          dtype, "bn_bwd_eval")
+    check(o.channel_sum(dev(dout)), emu.channel_sum(dout), torch.float32, "channel_sum", mult=10.0)
+    sc, sh = o.bn_eval_coeffs(gamma.to(DEV), beta.to(DEV), rm_g, rv_g, 1e-3)
+    sc_r, sh_r = emu.bn_eval_coeffs(gamma, beta, rm, rv, 1e-3)
+    check(sc, sc_r, torch.float32, "eval scale"), check(sh, sh_r, torch.float32, "eval shift")
+
+
+# ------------------------------------------------------------------------------------------ pool / upsample
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool5_and_upsample(dtype):
+    o = ops()
+    x = nhwc((rnd(2, 24, 9, 10, seed=40) * 2).round().div(2).to(dtype))        # many exact ties
+    out, idx = o.maxpool5_fwd(dev(x))
+    out_ref, idx_ref = emu.maxpool5_fwd(x)
+    assert torch.equal(out.cpu(), out_ref)
+    dout = nhwc(rnd(2, 24, 9, 10, seed=41).to(dtype))
+    check(o.maxpool5_bwd(dev(dout), idx), emu.maxpool5_bwd(dout, idx_ref), dtype, "maxpool5_bwd (tie routing)", mult=2.0)
+    up = o.upsample2x_fwd(dev(x))
+    assert torch.equal(up.cpu(), emu.upsample2x_fwd(x))
+    dup = nhwc(rnd(2, 24, 18, 20, seed=42).to(dtype))
+    check(o.upsample2x_bwd(dev(dup)), emu.upsample2x_bwd(dup), dtype, "upsample2x_bwd", mult=2.0)
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,dk,dh,h,w", [(2, 32, 64, 6, 6), (4, 32, 64, 20, 20), (1, 16, 32, 13, 11)])
+def test_attention(dtype, heads, dk, dh, h, w):
+    o = ops()
+    n = 2
+    qkv = nhwc(rnd(n, heads * (2 * dk + dh), h, w, seed=50).to(dtype))
+    scale = dk ** -0.5
+    og, vg, lse = o.attn_fwd(dev(qkv), heads, dk, dh, scale)
+    o_ref, v_ref, lse_ref = emu.attn_fwd(qkv, heads, dk, dh, scale)
+    check(og, o_ref, dtype, "attn o"), check(lse, lse_ref, torch.float32, "lse", mult=4.0)
+    assert torch.equal(vg.cpu(), v_ref)
+    d_o, d_v = nhwc(rnd(n, heads * dh, h, w, seed=51).to(dtype)), nhwc(rnd(n, heads * dh, h, w, seed=52).to(dtype))
+    dq = o.attn_bwd(dev(qkv), og, dev(d_o), dev(d_v), lse, heads, dk, dh, scale)
+    dq_ref = emu.attn_bwd(qkv, o_ref, d_o, d_v, lse_ref, heads, dk, dh, scale)
+    check(dq, dq_ref, dtype, "attn dqkv", mult=4.0)
+
+
+# ------------------------------------------------------------------------------------------ loss
+def _pack(gts):
+    from src.model.losses import PackedTargets
+    return PackedTargets([g.to(DEV) for g in gts], DEV)
+
+
+def _loss_case(preds, gts, anchors, strides, nc, dtype, lam=(1.5, 1.0)):
+    o = ops()
+    pk = _pack(gts)
+    p = preds.to(dtype)
+    out, dp, ws = o.loss_fwd_bwd(p.to(DEV), anchors.to(dtype).to(DEV), strides.to(dtype).to(DEV), *pk.as_tuple(), nc,
+                                 lam[0], lam[1], True)
+    ref_out, ref_dp, _ = emu.loss_fwd_bwd(p, anchors, strides, pk.gt.cpu(), pk.gt_off.cpu(), pk.gt_img.cpu(), pk.n_gt, nc,
+                                          lam[0], lam[1], True)
+    n, _, a = preds.shape
+    idx = ws[n * a * 16:n * a * 16 + 4 * max(pk.n_gt, 1)].view(torch.int32)[:pk.n_gt].cpu()
+    return out.cpu(), dp.float().cpu(), ref_out, ref_dp.float(), idx
+
+
+def test_loss_golden_small_fp32():
+    gd = load_golden("loss_small")
+    gts = [gd["gt0"], gd["gt1"].reshape(0, 5), gd["gt2"]]
+    out, dp, ref_out, ref_dp, _ = _loss_case(gd["preds"], gts, gd["anchors"], gd["strides"], 8, torch.float32)
+    want = torch.tensor([float(gd["total"]), float(gd["box"]), float(gd["cls"])])
+    assert torch.allclose(out, want, rtol=1e-5, atol=1e-6), (out, want)           # vs the reference itself
+    assert torch.allclose(dp, gd["dpreds"], rtol=1e-4, atol=1e-7), float((dp - gd["dpreds"]).abs().max())
+
+
+def test_loss_golden_n320_fp32():
+    from test_oracle_golden import n320_inputs
+    gd, preds, gts, a, s = n320_inputs()
+    out, dp, ref_out, ref_dp, _ = _loss_case(preds, gts, a, s, 80, torch.float32)
+    want = torch.tensor([float(gd["total"]), float(gd["box"]), float(gd["cls"])])
+    assert torch.allclose(out, want, rtol=1e-5, atol=1e-6), (out, want)
+    assert torch.allclose(dp[:, :, ::25], gd["dpreds_stride25"], rtol=1e-4, atol=1e-9)
+    assert abs(float(dp.double().abs().sum()) - float(gd["dpreds_abs"])) <= 1e-5 * float(gd["dpreds_abs"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss_random_s640_shape(dtype):
+    """N=4, A=8400, nc=80, 1..20 GTs per image (COCO-shaped synthetic targets)."""
+    from oracle.blocks import make_anchors
+    g = torch.Generator().manual_seed(70)
+    preds = torch.randn(4, 144, 8400, generator=g)
+    preds[:, 64:] = preds[:, 64:] * 0.7 - 3.5
+    a, s = make_anchors([(80, 80), (40, 40), (20, 20)], [8.0, 16.0, 32.0])
+    gts = []
+    for i in range(4):
+        m = int(torch.randint(1, 21, (1,), generator=g))
+        gts.append(torch.cat([torch.rand(m, 2, generator=g) * 640, torch.rand(m, 2, generator=g) * 256 + 8,
+                              torch.randint(0, 80, (m, 1), generator=g).float()], 1))
+    out, dp, ref_out, ref_dp, idx = _loss_case(preds, gts, a.t().contiguous(), s.t().contiguous(), 80, dtype)
+    assert torch.allclose(out, ref_out, rtol=1e-4 if dtype == torch.float32 else 1e-3, atol=1e-6), (out, ref_out)
+    lim = 1e-4 if dtype == torch.float32 else 2.0 ** -6
+    err = float((dp - ref_dp).abs().max()) / float(ref_dp.abs().max())
+    assert err <= lim, err
+
+
+# ------------------------------------------------------------------------------------------ decode / NMS
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_head_decode_and_dfl(dtype):
+    o = ops()
+    gd = load_golden("decode_val")
+    p = gd["preds"].to(dtype)
+    y = o.head_decode(p.to(DEV), gd["anchors"].to(DEV), gd["strides"].to(DEV), 8)
+    check(y, emu.head_decode(p, gd["anchors"], gd["strides"], 8), dtype, "head_decode")
+    x = load_golden("block_dfl")["x"].to(dtype)
+    check(o.dfl_expect(x.to(DEV)), emu.dfl_expect(x), dtype, "dfl_expect")
+
+
+def _nms_compare(pred, nc, **kw):
+    from src.utils.model_utils import non_max_suppression
+    from oracle.postproc import non_max_suppression as ref_nms
+    got = non_max_suppression(pred.to(DEV), nc=nc, **kw)
+    want = ref_nms(pred.clone(), nc=nc, **kw)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape, (i, g.shape, w.shape)
+        assert torch.equal(g.cpu(), w.float()), f"image {i}: rows differ"
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("default", dict(conf_thres=0.25, iou_thres=0.45)), ("agnostic", dict(conf_thres=0.25, iou_thres=0.45, agnostic=True)),
+    ("multi", dict(conf_thres=0.6, iou_thres=0.5, multi_label=True)), ("classes", dict(conf_thres=0.25, iou_thres=0.45, classes=[1, 3, 6])),
+    ("maxdet", dict(conf_thres=0.25, iou_thres=0.9, max_det=17)), ("highconf", dict(conf_thres=0.999, iou_thres=0.45))])
+def test_nms_golden_rows_exact(tag, kw):
+    from src.utils.model_utils import non_max_suppression
+    gd = load_golden("nms")
+    got = non_max_suppression(gd["prediction"].to(DEV), nc=8, **kw)
+    for i in range(2):
+        want = gd[f"{tag}:{i}"]
+        want = want.reshape(-1, 6) if isinstance(want, torch.Tensor) else torch.zeros(0, 6)
+        assert got[i].shape == want.shape, (tag, i, got[i].shape, want.shape)
+        assert torch.equal(got[i].cpu(), want), (tag, i)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_nms_stress_config5_shape(dtype):
+    """(bs, 84, 33600), thousands of candidates, >= 300 kept: BASELINE config 5's NMS tensor."""
+    g = torch.Generator().manual_seed(90)
+    m = 33600
+    pred = torch.empty(2, 84, m)
+    pred[:, 0:2] = torch.rand(2, 2, m, generator=g) * 1280
+    pred[:, 2:4] = torch.rand(2, 2, m, generator=g) * 120 + 10
+    pred[:, 4:] = torch.rand(2, 80, m, generator=g) * 0.93
+    _nms_compare(pred.to(dtype), 80, conf_thres=0.9, iou_thres=0.45)
