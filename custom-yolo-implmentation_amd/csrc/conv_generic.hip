@@ -134,76 +134,101 @@ __global__ void k_unpack_wgrad(const float* __restrict__ dwp, int O, int I, int 
 template <typename T, int V, bool FLIP>
 __global__ void k_dw3x3(const T* __restrict__ x, int ldx, const float* __restrict__ w, T* __restrict__ y, int ldy,
                         int N, int H, int W, int C) {
+    // row-strided: a thread owns one channel group (its 9 x V taps live in registers), a workgroup walks
+    // image rows, threads of one group stride along the row -- no per-element index division
     const int cv = C / V;
-    long total = (long)N * H * W * cv;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long p = i / cv;
-        int cg = (int)(i - p * cv);
-        int ww = (int)(p % W);
-        long t = p / W;
-        int hh = (int)(t % H);
-        long n = t / H;
-        float acc[V];
+    const int tpr = cv < 256 ? cv : 256, rpb = 256 / tpr;
+    const int wl = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - wl * tpr);
+    if (wl >= rpb || cg >= cv) return;
+    float wt[9][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            int hs = hh + kh - 1;
-            if (hs < 0 || hs >= H) continue;
+        for (int j = 0; j < V; ++j) wt[t][j] = w[(cg * V + j) * 9 + (FLIP ? 8 - t : t)];
+    const int nrows = N * H;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / H, hh = row - n * H;
+        for (int ww = wl; ww < W; ww += rpb) {
+            float acc[V];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                int ws = ww + kw - 1;
-                if (ws < 0 || ws >= W) continue;
-                float a[V];
-                load_pack<T, V>(x + ((n * H + hs) * W + ws) * (long)ldx + cg * V, a);
-                int tap = FLIP ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw;
+            for (int j = 0; j < V; ++j) acc[j] = 0.f;
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], w[(cg * V + j) * 9 + tap], acc[j]);
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hs = hh + kh - 1;
+                if (hs < 0 || hs >= H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ws = ww + kw - 1;
+                    if (ws < 0 || ws >= W) continue;
+                    float a[V];
+                    load_pack<T, V>(x + (((long)n * H + hs) * W + ws) * ldx + cg * V, a);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], wt[kh * 3 + kw][j], acc[j]);
+                }
             }
+            store_pack<T, V>(y + ((long)row * W + ww) * ldy + cg * V, acc);
         }
-        store_pack<T, V>(y + p * (long)ldy + cg * V, acc);
     }
 }
 
 // dw[c][tap] += sum_p dy[p][c] * x[p (+) tap][c]; block = 64 channels x 4 row-lanes, slab of rows
-template <typename T>
+// Same thread mapping as k_dw3x3; each thread keeps 9 x V partial sums, the workgroup combines them
+// through LDS one tap at a time and issues one atomic per (channel, tap).
+template <typename T, int V>
 __global__ void k_dw3x3_wgrad(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int ldy,
                               float* __restrict__ dw, int N, int H, int W, int C, int rows_per_slab) {
-    __shared__ float red[4][64][9];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float acc[9];
+    __shared__ float red[256][V + 1];
+    const int cv = C / V;
+    const int tpr = cv < 256 ? cv : 256, rpb = 256 / tpr;
+    const int wl = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - wl * tpr);
+    const bool active = wl < rpb && cg < cv;
+    float acc[9][V];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-    long r0 = (long)blockIdx.y * rows_per_slab, r1 = r0 + rows_per_slab, nrows = (long)N * H;
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[t][j] = 0.f;
+    const int nrows = N * H;
+    int r0 = blockIdx.x * rows_per_slab, r1 = r0 + rows_per_slab;
     if (r1 > nrows) r1 = nrows;
-    if (c < C) {
-        for (long r = r0 + rl; r < r1; r += 4) {
-            long n = r / H;
-            int hh = (int)(r - n * H);
-            for (int ww = 0; ww < W; ++ww) {
-                float g = to_f<T>(dy[(r * W + ww) * (long)ldy + c]);
+    if (active) {
+        for (int row = r0; row < r1; ++row) {
+            const int n = row / H, hh = row - n * H;
+            for (int ww = wl; ww < W; ww += rpb) {
+                float g[V];
+                load_pack<T, V>(dy + ((long)row * W + ww) * ldy + cg * V, g);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
-                    int hs = hh + kh - 1;
+                    const int hs = hh + kh - 1;
                     if (hs < 0 || hs >= H) continue;
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        int ws = ww + kw - 1;
+                        const int ws = ww + kw - 1;
                         if (ws < 0 || ws >= W) continue;
-                        acc[kh * 3 + kw] = fmaf(g, to_f<T>(x[((n * H + hs) * W + ws) * (long)ldx + c]), acc[kh * 3 + kw]);
+                        float a[V];
+                        load_pack<T, V>(x + (((long)n * H + hs) * W + ws) * ldx + cg * V, a);
+#pragma unroll
+                        for (int j = 0; j < V; ++j) acc[kh * 3 + kw][j] = fmaf(g[j], a[j], acc[kh * 3 + kw][j]);
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[rl][cl][t] = acc[t];
-    __syncthreads();
-    if (rl == 0 && c < C) {
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-            atomicAdd(dw + (long)c * 9 + t, red[0][cl][t] + red[1][cl][t] + red[2][cl][t] + red[3][cl][t]);
+        for (int j = 0; j < V; ++j) red[threadIdx.x][j] = acc[t][j];
+        __syncthreads();
+        if (wl == 0 && cg < cv) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float s = 0.f;
+                for (int rr = 0; rr < rpb; ++rr) s += red[threadIdx.x + rr * tpr][j];
+                atomicAdd(dw + (long)(cg * V + j) * 9 + t, s);
+            }
+        }
     }
 }
 
@@ -381,35 +406,40 @@ int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw
     return YOLO_LAUNCH_CHECK();
 }
 
+}  // extern "C"
+
 // depthwise 3x3 stride 1 pad 1; w = fp32 [C][9]
-int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
-                       hipStream_t st) {
+static dim3 dw_grid(int nrows, int cv) {
+    int tpr = cv < 256 ? cv : 256;
+    return dim3((unsigned)(nrows < 4096 ? nrows : 4096), (unsigned)ceil_div(cv, tpr));
+}
+
+template <bool FLIP>
+static int dw_launch(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
+                     hipStream_t st) {
     YOLO_DISPATCH_T(dtype, {
         if (vecok<T>(x, ldx, C) && vecok<T>(y, ldy, C)) {
             constexpr int V = vec_of<T>::N;
-            hipLaunchKernelGGL((k_dw3x3<T, V, false>), dim3(grid_for((long)N * H * W * (C / V))), dim3(256), 0, st,
-                               (const T*)x, ldx, w, (T*)y, ldy, N, H, W, C);
+            hipLaunchKernelGGL((k_dw3x3<T, V, FLIP>), dw_grid(N * H, C / V), dim3(256), 0, st, (const T*)x, ldx, w, (T*)y,
+                               ldy, N, H, W, C);
         } else {
-            hipLaunchKernelGGL((k_dw3x3<T, 1, false>), dim3(grid_for((long)N * H * W * C)), dim3(256), 0, st, (const T*)x,
-                               ldx, w, (T*)y, ldy, N, H, W, C);
+            hipLaunchKernelGGL((k_dw3x3<T, 1, FLIP>), dw_grid(N * H, C), dim3(256), 0, st, (const T*)x, ldx, w, (T*)y, ldy,
+                               N, H, W, C);
         }
     });
     return YOLO_LAUNCH_CHECK();
 }
 
+extern "C" {
+
+int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
+                       hipStream_t st) {
+    return dw_launch<false>(x, ldx, w, y, ldy, N, H, W, C, dtype, st);
+}
+
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C,
                          int dtype, hipStream_t st) {
-    YOLO_DISPATCH_T(dtype, {
-        if (vecok<T>(dy, lddy, C) && vecok<T>(dx, lddx, C)) {
-            constexpr int V = vec_of<T>::N;
-            hipLaunchKernelGGL((k_dw3x3<T, V, true>), dim3(grid_for((long)N * H * W * (C / V))), dim3(256), 0, st,
-                               (const T*)dy, lddy, w, (T*)dx, lddx, N, H, W, C);
-        } else {
-            hipLaunchKernelGGL((k_dw3x3<T, 1, true>), dim3(grid_for((long)N * H * W * C)), dim3(256), 0, st, (const T*)dy,
-                               lddy, w, (T*)dx, lddx, N, H, W, C);
-        }
-    });
-    return YOLO_LAUNCH_CHECK();
+    return dw_launch<true>(dy, lddy, w, dx, lddx, N, H, W, C, dtype, st);
 }
 
 // dw fp32 [C][9], zeroed here
@@ -417,15 +447,22 @@ int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float*
                          int dtype, hipStream_t st) {
     int rc = hip_status(hipMemsetAsync(dw, 0, (size_t)C * 9 * sizeof(float), st));
     if (rc) return rc;
-    long nrows = (long)N * H;
-    int gx = ceil_div(C, 64);
-    long want = 2048 / gx;
-    if (want < 1) want = 1;
-    if (want > nrows) want = nrows;
-    int rps = (int)((nrows + want - 1) / want);
-    int gy = (int)((nrows + rps - 1) / rps);
-    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw3x3_wgrad<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, ldx,
-                                              (const T*)dy, ldy, dw, N, H, W, C, rps));
+    int nrows = N * H;
+    int slabs = nrows < 1024 ? nrows : 1024;
+    int rps = (nrows + slabs - 1) / slabs;
+    slabs = (nrows + rps - 1) / rps;
+    YOLO_DISPATCH_T(dtype, {
+        if (vecok<T>(x, ldx, C) && vecok<T>(dy, ldy, C)) {
+            constexpr int V = vec_of<T>::N;
+            int cv = C / V, tpr = cv < 256 ? cv : 256;
+            hipLaunchKernelGGL((k_dw3x3_wgrad<T, V>), dim3(slabs, ceil_div(cv, tpr)), dim3(256), 0, st, (const T*)x, ldx,
+                               (const T*)dy, ldy, dw, N, H, W, C, rps);
+        } else {
+            int tpr = C < 256 ? C : 256;
+            hipLaunchKernelGGL((k_dw3x3_wgrad<T, 1>), dim3(slabs, ceil_div(C, tpr)), dim3(256), 0, st, (const T*)x, ldx,
+                               (const T*)dy, ldy, dw, N, H, W, C, rps);
+        }
+    });
     return YOLO_LAUNCH_CHECK();
 }
 

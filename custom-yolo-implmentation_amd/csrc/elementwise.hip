@@ -142,6 +142,30 @@ __global__ void k_channel_reduce(const T* __restrict__ y, int ldy, const T* __re
     }
 }
 
+// Finalize kernels run as (32 channels x 32 parts) 1024-thread workgroups: part j sums partial blocks
+// j, j+32, ... of its channel (128-byte coalesced rows), LDS combines the 32 parts; the thread with
+// part 0 gets the totals and returns its channel, the others return -1.  (A one-thread-per-channel
+// loop over 512 partials cost ~95 us per launch, 15 ms per training step.)
+constexpr int FIN_CH = 32, FIN_PARTS = 32;
+__device__ __forceinline__ int fin_reduce(const float* __restrict__ partial, int nblk, int C, double& s, double& q) {
+    __shared__ double red[2][FIN_PARTS][FIN_CH + 1];
+    const int cl = threadIdx.x & (FIN_CH - 1), part = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cl;
+    double ls = 0.0, lq = 0.0;
+    if (c < C)
+        for (int b = part; b < nblk; b += FIN_PARTS) {
+            ls += partial[(long)b * 2 * C + c];
+            lq += partial[(long)b * 2 * C + C + c];
+        }
+    red[0][part][cl] = ls;
+    red[1][part][cl] = lq;
+    __syncthreads();
+    if (part != 0 || c >= C) return -1;
+    s = 0.0; q = 0.0;
+    for (int j = 0; j < FIN_PARTS; ++j) { s += red[0][j][cl]; q += red[1][j][cl]; }
+    return c;
+}
+
 // finalize for training-mode BN: batch mean / biased var -> invstd, scale, shift; running stats
 // updated with momentum and the unbiased variance (torch.nn.BatchNorm2d semantics).
 __global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, float count, int C,
@@ -149,10 +173,9 @@ __global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, float
                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                               float* __restrict__ mean, float* __restrict__ invstd,
                               float* __restrict__ scale, float* __restrict__ shift) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[(long)b * 2 * C + c]; q += partial[(long)b * 2 * C + C + c]; }
+    double s, q;
+    const int c = fin_reduce(partial, nblk, C, s, q);
+    if (c < 0) return;
     double m = s / count;
     double var = q / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -181,25 +204,24 @@ __global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* _
 
 // backward finalize: dgamma = sum dz*yhat, dbeta = sum dz, coef = [gamma*invstd, dbeta/m, dgamma/m]
 __global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, float count, int C,
-                                  const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                  const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[(long)b * 2 * C + c]; q += partial[(long)b * 2 * C + C + c]; }
+    double s, q;
+    const int c = fin_reduce(partial, nblk, C, s, q);
+    if (c < 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
-    coef[c] = gamma[c] * invstd[c];
-    coef[C + c] = (float)(s / count);
-    coef[2 * C + c] = (float)(q / count);
+    // dy = k0*(dz - c1 - yhat*c2), yhat = (y-mean)*invstd  ==  A*dz + B*y + D  (three constants per channel)
+    const double k0 = (double)gamma[c] * invstd[c], c1 = s / count, c2 = q / count;
+    coef[c] = (float)k0;
+    coef[C + c] = (float)(-k0 * c2 * invstd[c]);
+    coef[2 * C + c] = (float)(-k0 * c1 + k0 * c2 * (double)mean[c] * invstd[c]);
 }
 
 __global__ void k_sum_finalize(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 2 * C + c];
-    out[c] = (float)s;
+    double s, q;
+    const int c = fin_reduce(partial, nblk, C, s, q);
+    if (c >= 0) out[c] = (float)s;
 }
 
 // out = act(y*scale + shift) (+ res)
@@ -207,21 +229,42 @@ template <typename T, int V>
 __global__ void k_bn_act_fwd(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                              const float* __restrict__ shift, const T* __restrict__ res, int ldr,
                              T* __restrict__ out, int ldo, long npix, int cv, int act) {
-    long total = npix * cv;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long p = i / cv;
-        int cg = (int)(i - p * cv);
-        float a[V];
+    // row-strided: a thread keeps ONE channel group (its scale/shift live in registers) and walks pixels;
+    // no per-element index division, two pixels in flight per iteration
+    const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    const int r = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    if (r >= rpb || cg >= cv) return;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = scale[cg * V + j]; sh[j] = shift[cg * V + j]; }
+    const long step = (long)gridDim.x * rpb;
+    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
+        const long p2 = p + step;
+        const bool two = p2 < npix;
+        float a[V], b[V];
         load_pack<T, V>(y + p * ldy + cg * V, a);
+        if (two) load_pack<T, V>(y + p2 * ldy + cg * V, b);
 #pragma unroll
-        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * scale[cg * V + j] + shift[cg * V + j], act);
+        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], act);
         if (res) {
-            float r[V];
-            load_pack<T, V>(res + p * ldr + cg * V, r);
+            float t[V];
+            load_pack<T, V>(res + p * ldr + cg * V, t);
 #pragma unroll
-            for (int j = 0; j < V; ++j) a[j] += r[j];
+            for (int j = 0; j < V; ++j) a[j] += t[j];
         }
         store_pack<T, V>(out + p * ldo + cg * V, a);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) b[j] = act_fwd(b[j] * sc[j] + sh[j], act);
+            if (res) {
+                float t[V];
+                load_pack<T, V>(res + p2 * ldr + cg * V, t);
+#pragma unroll
+                for (int j = 0; j < V; ++j) b[j] += t[j];
+            }
+            store_pack<T, V>(out + p2 * ldo + cg * V, b);
+        }
     }
 }
 
@@ -232,26 +275,41 @@ __global__ void k_bn_act_bwd_apply(const T* __restrict__ dout, int ldd, const T*
                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                    const float* __restrict__ coef, T* __restrict__ dy, int lddy,
                                    long npix, int C, int act) {
+    // dy = A*dz + B*y + D with (A, B, D) = coef rows from k_bn_bwd_finalize; frozen statistics: (scale, 0, 0)
     const int cv = C / V;
-    long total = npix * cv;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long p = i / cv;
-        int cg = (int)(i - p * cv);
-        float a[V], d[V];
+    const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    const int r = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    if (r >= rpb || cg >= cv) return;
+    float sc[V], sh[V], cA[V], cB[V], cD[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cg * V + j;
+        sc[j] = scale[c]; sh[j] = shift[c];
+        cA[j] = coef ? coef[c] : scale[c];
+        cB[j] = coef ? coef[C + c] : 0.f;
+        cD[j] = coef ? coef[2 * C + c] : 0.f;
+    }
+    const long step = (long)gridDim.x * rpb;
+    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
+        const long p2 = p + step;
+        const bool two = p2 < npix;
+        float a[V], d[V], a2[V], d2[V];
         load_pack<T, V>(y + p * ldy + cg * V, a);
         load_pack<T, V>(dout + p * ldd + cg * V, d);
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            int c = cg * V + j;
-            float dz = d[j] * act_grad(a[j] * scale[c] + shift[c], act);
-            if (coef) {
-                float yh = (a[j] - mean[c]) * invstd[c];
-                d[j] = coef[c] * (dz - coef[C + c] - yh * coef[2 * C + c]);
-            } else {
-                d[j] = scale[c] * dz;
-            }
+        if (two) {
+            load_pack<T, V>(y + p2 * ldy + cg * V, a2);
+            load_pack<T, V>(dout + p2 * ldd + cg * V, d2);
         }
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = cA[j] * (d[j] * act_grad(a[j] * sc[j] + sh[j], act)) + cB[j] * a[j] + cD[j];
         store_pack<T, V>(dy + p * lddy + cg * V, d);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+                d2[j] = cA[j] * (d2[j] * act_grad(a2[j] * sc[j] + sh[j], act)) + cB[j] * a2[j] + cD[j];
+            store_pack<T, V>(dy + p2 * lddy + cg * V, d2);
+        }
     }
 }
 
@@ -388,6 +446,15 @@ __global__ void k_upsample2x_bwd(const T* __restrict__ dout, int ldd, T* __restr
     }
 }
 
+// grid of a row-strided kernel: x walks pixel rows (2 per thread per iteration), y covers channel groups > 256
+inline dim3 rs_grid(long npix, int cv) {
+    int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    long gx = (npix + 2L * rpb - 1) / (2L * rpb);
+    if (gx > 256 * 12) gx = 256 * 12;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)ceil_div(cv, tpr));
+}
+
 inline int ew_grid(long total) {
     long b = (total + TPB - 1) / TPB;
     return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));   // <= 16 blocks per CU, grid-stride the rest
@@ -495,7 +562,7 @@ int yolo_bn_stats(const void* y, int ldy, long npix, int C, int dtype, float* pa
 int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, float* mean,
                      float* invstd, float* scale, float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 128)), dim3(128), 0, st, partial, nblk, (float)count, C, gamma,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk, (float)count, C, gamma,
                        beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return YOLO_LAUNCH_CHECK();
 }
@@ -508,7 +575,7 @@ int yolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 }
 
 int yolo_sum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_sum_finalize, dim3(ceil_div(C, 128)), dim3(128), 0, st, partial, nblk, C, out);
+    hipLaunchKernelGGL(k_sum_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk, C, out);
     return YOLO_LAUNCH_CHECK();
 }
 
@@ -518,7 +585,7 @@ int yolo_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shi
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(out, ldout, C) && (!res || vec_ok<T>(res, ldres, C));
         PICK_V(T, ok, {
             int cv = C / V;
-            hipLaunchKernelGGL((k_bn_act_fwd<T, V>), dim3(ew_grid(npix * cv)), dim3(TPB), 0, st, (const T*)y, ldy, scale,
+            hipLaunchKernelGGL((k_bn_act_fwd<T, V>), rs_grid(npix, cv), dim3(TPB), 0, st, (const T*)y, ldy, scale,
                                shift, (const T*)res, ldres, (T*)out, ldout, npix, cv, act);
         });
     });
@@ -531,10 +598,10 @@ int yolo_bn_act_bwd_reduce(const void* dout, int ldd, const void* y, int ldy, co
     return launch_reduce(1, y, ldy, dout, ldd, scale, shift, mean, invstd, npix, C, act, dtype, partial, nblk, st);
 }
 
-int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* invstd,
-                         float* dgamma, float* dbeta, float* coef, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 128)), dim3(128), 0, st, partial, nblk, (float)count, C,
-                       gamma, invstd, dgamma, dbeta, coef);
+int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* mean,
+                         const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk,
+                       (float)count, C, gamma, mean, invstd, dgamma, dbeta, coef);
     return YOLO_LAUNCH_CHECK();
 }
 
@@ -545,7 +612,7 @@ int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, con
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(dout, ldd, C) && vec_ok<T>(dy, lddy, C);
         PICK_V(T, ok, {
             int cv = C / V;
-            hipLaunchKernelGGL((k_bn_act_bwd_apply<T, V>), dim3(ew_grid(npix * cv)), dim3(TPB), 0, st, (const T*)dout,
+            hipLaunchKernelGGL((k_bn_act_bwd_apply<T, V>), rs_grid(npix, cv), dim3(TPB), 0, st, (const T*)dout,
                                ldd, (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, npix, C, act);
         });
     });

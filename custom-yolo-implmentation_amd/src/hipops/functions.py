@@ -38,12 +38,19 @@ class ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps):
         T = compute_dtype(x, weight)
-        x = _as_nhwc(x, T)
         cout = weight.shape[0]
-        if depthwise:
+        # stem: a 3-channel image feeding a 3x3/2 conv is unfolded once (from NCHW directly) and then
+        # runs as a 1x1 conv over K = 32 columns; x (saved for wgrad) becomes that column tensor
+        stem = (not depthwise and weight.shape[1] == 3 and k == 3 and stride == 2 and not ctx.needs_input_grad[0])
+        if stem:
+            x = ops.stem_im2col(x, T)
+            y = ops.conv_fwd(x, ops.stem_pack_weights(weight, T), None, cout, 1, 1)
+        elif depthwise:
+            x = _as_nhwc(x, T)
             w9 = _f32(weight).reshape(cout, 9)
             y = ops.dw_fwd(x, w9)
         else:
+            x = _as_nhwc(x, T)
             y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride)
         g32, b32 = _f32(gamma), _f32(beta)
         rm, rv = bufs
@@ -59,13 +66,13 @@ class ConvBnAct(torch.autograd.Function):
         if res is not None:
             res = _as_nhwc(res, T)
         out = ops.bn_act_fwd(y, scale, shift, act, res)
-        ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype)
+        ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype, stem)
         ctx.save_for_backward(x, weight, y, scale, shift, mean, invstd, g32)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        k, stride, depthwise, act, training, xshape, has_res, gdtype = ctx.cfg
+        k, stride, depthwise, act, training, xshape, has_res, gdtype, stem = ctx.cfg
         x, weight, y, scale, shift, mean, invstd, g32 = ctx.saved_tensors
         T = y.dtype
         dout = _as_nhwc(dout, T)
@@ -75,7 +82,10 @@ class ConvBnAct(torch.autograd.Function):
             dy, dgamma, dbeta = ops.bn_act_bwd_eval(dout, y, scale, shift, act), None, None
         dx = dw = None
         n, cin, h, w = xshape
-        if depthwise:
+        if stem:
+            if ctx.needs_input_grad[1]:
+                dw = ops.stem_unpack_wgrad(ops.conv_wgrad(x, dy, 1, 1, torch.float32), weight.dtype)
+        elif depthwise:
             if ctx.needs_input_grad[0]:
                 dx = ops.dw_dgrad(dy, _f32(weight).reshape(weight.shape[0], 9))
             if ctx.needs_input_grad[1]:

@@ -154,6 +154,33 @@ def conv_wgrad(x, dy, k, stride, w_dtype):
     return dw
 
 
+def stem_im2col(img, dtype):
+    """(N,3,H,W) NCHW image (any float dtype) -> NHWC (N,32,OH,OW) column tensor: K = ci*9+kh*3+kw, 27..31 zero."""
+    img = img if img.is_contiguous() else img.contiguous()
+    n, c, h, w = img.shape
+    assert c == 3
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    col = new_nhwc(n, 32, oh, ow, dtype, img.device)
+    lib.call("yolo_stem_im2col", _p(img), dt(img), _p(col), dt(dtype), n, h, w, oh, ow, _stream(img))
+    return col
+
+
+def stem_pack_weights(w, dtype):
+    """OIHW (Cout,3,3,3) -> forward-packed [Cout][32] matrix for conv_fwd(k=1) on the column tensor."""
+    w = w if w.is_contiguous() else w.contiguous()
+    out = torch.empty(w.shape[0] * 32, dtype=dtype, device=w.device)
+    lib.call("yolo_stem_pack_weights", _p(w), dt(w), w.shape[0], _p(out), dt(dtype), _stream(w))
+    return out
+
+
+def stem_unpack_wgrad(dw32, w_dtype):
+    """fp32 (Cout,32,1,1) gradient of the padded 1x1 weights -> (Cout,3,3,3) in the parameter dtype."""
+    cout = dw32.shape[0]
+    dw = torch.empty((cout, 3, 3, 3), dtype=w_dtype, device=dw32.device)
+    lib.call("yolo_stem_unpack_wgrad", _p(dw32), cout, _p(dw), dt(w_dtype), _stream(dw32))
+    return dw
+
+
 def dw_fwd(x, w9):
     n, c, h, w, ldx = geom(x)
     y = new_nhwc(n, c, h, w, x.dtype, x.device)
@@ -225,7 +252,8 @@ def bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act):
              int(act), dt(y), _p(part), nblk, st)
     buf = _f32(5 * c, y.device)
     dgamma, dbeta, coef = buf[:c], buf[c:2 * c], buf[2 * c:]
-    lib.call("yolo_bn_bwd_finalize", _p(part), nblk, npix, c, _p(gamma), _p(invstd), _p(dgamma), _p(dbeta), _p(coef), st)
+    lib.call("yolo_bn_bwd_finalize", _p(part), nblk, npix, c, _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta),
+             _p(coef), st)
     dy = new_nhwc(n, c, h, w, y.dtype, y.device)
     lib.call("yolo_bn_act_bwd_apply", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), _p(mean), _p(invstd), _p(coef),
              _p(dy), c, npix, c, int(act), dt(y), st)

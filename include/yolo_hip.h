@@ -53,6 +53,10 @@ int yolo_conv_unpack_wgrad(const float* dwp, int O, int I, int k, void* dw_oihw,
 int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dwp, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
+/* stem (3 -> C, 3x3 stride 2: backbone.py:38): NCHW image unfolded to K = 27(+5) columns, then the 1x1 MFMA path */
+int yolo_stem_im2col(const void* img, int img_dtype, void* col, int col_dtype, int N, int H, int W, int OH, int OW, hipStream_t st);
+int yolo_stem_pack_weights(const void* w, int w_dtype, int Cout, void* out, int out_dtype, hipStream_t st);
+int yolo_stem_unpack_wgrad(const float* dw32, int Cout, void* dw, int dw_dtype, hipStream_t st);
 /* depthwise 3x3 (groups == channels: model_blocks.py:183, head.py:56,58) */
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype, hipStream_t st);
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int dtype, hipStream_t st);
@@ -66,7 +70,7 @@ int yolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 int yolo_sum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st);
 int yolo_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype, hipStream_t st);
 int yolo_bn_act_bwd_reduce(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* partial, int nblk, hipStream_t st);
-int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st);
+int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st);
 int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, const float* coef, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
 
 /* ---- SPPF max pool (model_blocks.py:150-156) and nearest x2 upsample (neck.py:31,41-42) */

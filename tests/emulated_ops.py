@@ -72,6 +72,21 @@ def conv_wgrad(x, dy, k, stride, w_dtype):
     return dw.to(w_dtype)
 
 
+def stem_im2col(img, dtype):
+    n, c, h, w = img.shape
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    cols = F.unfold(img.float(), 3, padding=1, stride=2).view(n, 27, oh, ow)      # k = ci*9 + kh*3 + kw
+    return _nhwc(F.pad(cols, (0, 0, 0, 0, 0, 5)).to(dtype))
+
+
+def stem_pack_weights(w, dtype):
+    return F.pad(w.detach().reshape(w.shape[0], 27), (0, 5)).reshape(w.shape[0], 32, 1, 1).to(dtype)
+
+
+def stem_unpack_wgrad(dw32, w_dtype):
+    return dw32.reshape(dw32.shape[0], 32)[:, :27].reshape(-1, 3, 3, 3).to(w_dtype)
+
+
 def dw_fwd(x, w9):
     c = x.shape[1]
     return _nhwc(F.conv2d(x.float(), w9.view(c, 1, 3, 3), None, 1, 1, 1, c).to(x.dtype))
@@ -234,6 +249,7 @@ def nms(y, nc, conf_thres, iou_thres, classes, agnostic, multi_label, max_det):
 
 
 LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "zero_", "fill_", "pack_weights", "conv_fwd",
+          "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad",
           "conv_dgrad", "conv_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "bn_train_stats", "bn_eval_coeffs",
           "bn_act_fwd", "bn_act_bwd", "bn_act_bwd_eval", "channel_sum", "maxpool5_fwd", "maxpool5_bwd",
           "upsample2x_fwd", "upsample2x_bwd", "attn_fwd", "attn_bwd", "loss_fwd_bwd", "scale_inplace", "head_decode",

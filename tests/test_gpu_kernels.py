@@ -128,6 +128,24 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, algo, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("h,w", [(32, 32), (17, 23)])
+def test_stem_unfold_path(dtype, h, w):
+    o = ops()
+    img = rnd(3, 3, h, w, seed=15)
+    wt = rnd(16, 3, 3, 3, seed=16, scale=0.2)
+    col = o.stem_im2col(img.to(DEV), dtype)
+    col_ref = emu.stem_im2col(img, dtype)
+    assert torch.equal(col.cpu(), col_ref)
+    y = o.conv_fwd(col, o.stem_pack_weights(wt.to(DEV), dtype), None, 16, 1, 1)
+    y_ref = emu.conv_fwd(nhwc(torch.as_tensor(img).to(dtype)), emu.pack_weights(wt, 3, 2, 0, dtype), None, 16, 3, 2)
+    check(y, y_ref, dtype, "stem forward == 3x3/2 conv")
+    dy = nhwc(rnd(*y_ref.shape, seed=17).to(dtype))
+    dw = o.stem_unpack_wgrad(o.conv_wgrad(col, dev(dy), 1, 1, torch.float32), torch.float32)
+    dw_ref = emu.conv_wgrad(nhwc(img.to(dtype)), dy, 3, 2, torch.float32)
+    check(dw, dw_ref, torch.float32, "stem wgrad", mult=4.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("c,h,w", [(16, 12, 12), (24, 7, 9), (128, 10, 10)])
 def test_depthwise(dtype, c, h, w):
     o = ops()
