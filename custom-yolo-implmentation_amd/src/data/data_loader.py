@@ -1,0 +1,47 @@
+"""Data loaders with the reference's entry point (src/data/data_loader.py:11).  The parquet/PIL pipeline
+is outside the accelerated path; when the parquet directory is absent this returns
+loaders over the synthetic COCO-shaped dataset the benchmark uses, in the same (images, [targets]) format."""
+import os
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+from src.data.collate import collate_fn
+
+
+class SyntheticDetectionDataset(Dataset):
+    """randn images; 1..20 boxes (cx,cy,w,h,cls) in pixels per image."""
+
+    def __init__(self, length=64, res=640, num_classes=80, seed=1234):
+        self.length, self.res, self.nc, self.seed = length, res, num_classes, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed + i)
+        img = torch.randn(3, self.res, self.res, generator=g)
+        m = int(torch.randint(1, 21, (1,), generator=g))
+        boxes = torch.cat([torch.rand(m, 2, generator=g) * self.res, torch.rand(m, 2, generator=g) * (0.4 * self.res) + 8,
+                           torch.randint(0, self.nc, (m, 1), generator=g).float()], 1)
+        return img, {"boxes": boxes}
+
+
+def get_data_loaders(train_parquet, val_parquet, train_images, val_images, batch_size, is_test=False, prefetch_factor=2,
+                     percent=1.0, device="cpu", num_classes=80, res=640):
+    if os.path.exists(train_parquet):
+        raise NotImplementedError("parquet/PIL input pipeline is outside this build's scope (SURVEY 8f); "
+                                  "remove the parquet path to train on the synthetic dataset")
+    n = 20 if is_test else 256
+    train_ds = SyntheticDetectionDataset(max(batch_size, int(n * percent)), res, num_classes, 1234)
+    val_ds = SyntheticDetectionDataset(max(batch_size, int(n * percent) // 4), res, num_classes, 4321)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    ts = DistributedSampler(train_ds, shuffle=True) if dist_on else None
+    vs = DistributedSampler(val_ds, shuffle=False) if dist_on else None
+    pin = device == "cuda"
+    train = DataLoader(train_ds, batch_size=batch_size, shuffle=ts is None, sampler=ts, num_workers=0, pin_memory=pin,
+                       collate_fn=collate_fn, drop_last=True)
+    val = DataLoader(val_ds, batch_size=batch_size, shuffle=False, sampler=vs, num_workers=0, pin_memory=pin,
+                     collate_fn=collate_fn)
+    return train, val

@@ -1,0 +1,145 @@
+"""Training / validation loop and validation decode with the reference's signatures
+(src/training/train_model.py:14-142 decode_predictions, :145-384 train).
+
+Same step body as the reference -- zero_grad, autocast only in ddp mode, forward, loss, (scaled) backward,
+optimizer step -- on the HIP-backed model; host-side changes only: the three loss scalars arrive with one
+device->host copy per step (LazyLossDict) and the six per-epoch scalar all-reduces are two."""
+import torch
+from torch.amp import GradScaler
+from tqdm import tqdm
+
+try:
+    from torch.distributed.fsdp.sharded_grad_scaler import ShardedGradScaler
+except ImportError:  # pragma: no cover
+    ShardedGradScaler = None
+
+from src.hipops import ops
+from src.training.distributed_setup import reduce_values
+from src.training.metrics import DetectionMetrics
+from src.training.utils_train import save_checkpoint
+
+
+def decode_predictions(preds, anchors, strides, conf_threshold=0.25, top_k=100, num_classes=171):
+    """Raw head output -> per image (k, 5) [cx, cy, w, h, class]: DFL expectation -> xywh * stride (one fused
+    kernel), sigmoid best class, confidence filter, top-k by score; no NMS (reference :14-142)."""
+    n, cp, m = preds.shape
+    nc = cp - 64
+    y = ops.head_decode(preds, anchors, strides, nc)            # (N, 4+nc, M): boxes + raw class logits
+    out = []
+    for b in range(n):
+        score, cls = y[b, 4:].transpose(0, 1).sigmoid().max(dim=1)
+        keep = score >= conf_threshold
+        boxes, score, cls = y[b, :4].transpose(0, 1)[keep], score[keep], cls[keep]
+        if boxes.numel() == 0:
+            out.append(torch.zeros(0, 5, device=preds.device))
+            continue
+        if score.numel() > top_k:
+            top = torch.topk(score, top_k)[1]
+            boxes, cls = boxes[top], cls[top]
+        out.append(torch.cat([boxes, cls.unsqueeze(1).to(boxes.dtype)], dim=1).float())
+    return out
+
+
+def _make_scaler(precision, distributed_mode, device, rank):
+    if precision != "float16":
+        if precision == "bfloat16" and rank == 0:
+            print("[INFO] Using bfloat16 precision (no scaler needed)")
+        return None
+    on_gpu = device != "cpu"
+    if distributed_mode.startswith("fsdp") and on_gpu and ShardedGradScaler is not None:
+        if rank == 0:
+            print("[INFO] Initialized ShardedGradScaler for FSDP float16 training")
+        return ShardedGradScaler()
+    if rank == 0:
+        print(f"[INFO] Initialized GradScaler for {distributed_mode} float16 training on {device}")
+    return GradScaler("cuda" if on_gpu else "cpu")
+
+
+def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimizer=None, scaler=None, metrics=None,
+               conf_threshold=0.25, num_classes=171, on_step=None):
+    sums = [0.0, 0.0, 0.0]
+    bar = tqdm(loader, desc=desc, disable=(rank != 0))
+    for i, (images, targets) in enumerate(bar):
+        images = images.to(device)
+        gt_box = [t["boxes"].to(device) for t in targets]
+        if optimizer is not None:
+            optimizer.zero_grad()
+        with torch.autocast(**autocast_kw):
+            preds, anchors, strides = model(images)
+            loss, loss_dict = criterion(preds, gt_box, anchors, strides)
+        if optimizer is not None:
+            if scaler is not None:
+                scaler.scale(loss).backward()
+                scaler.step(optimizer)
+                scaler.update()
+            else:
+                loss.backward()
+                optimizer.step()
+        elif metrics is not None:
+            for pred, gt in zip(decode_predictions(preds, anchors, strides, conf_threshold=conf_threshold,
+                                                   num_classes=num_classes), gt_box):
+                if gt.numel() > 0:
+                    metrics.update(pred, gt)
+        for k, key in enumerate(("total_loss", "box_loss", "cls_loss")):
+            sums[k] += loss_dict[key]
+        bar.set_postfix({"Loss": f"{sums[0] / (i + 1):.4f}", "Box": f"{sums[1] / (i + 1):.4f}",
+                         "Cls": f"{sums[2] / (i + 1):.4f}"})
+        if on_step is not None:
+            on_step(i, loss_dict)
+    n = max(len(loader), 1)
+    return [s / n for s in sums]
+
+
+def train(model, train_loader, val_loader, optimizer, scheduler, criterion, initial_epoch, num_epochs, device,
+          num_classes=171, rank=0, use_wandb=False, wandb_instance=None, log_interval=10,
+          checkpoint_dir="experiments/checkpoints", iou_threshold=0.5, conf_threshold=0.25, distributed_mode="ddp",
+          precision="float32"):
+    use_amp = precision in ("float16", "bfloat16")
+    scaler = _make_scaler(precision, distributed_mode, device, rank) if use_amp else None
+    autocast_kw = dict(device_type="cpu" if device == "cpu" else "cuda",
+                       dtype=torch.bfloat16 if precision == "bfloat16" else torch.float16,
+                       enabled=(distributed_mode == "ddp" and use_amp))       # FSDP modes rely on their MP policy
+    metrics = DetectionMetrics(num_classes=num_classes, iou_threshold=iou_threshold)
+
+    for epoch in range(initial_epoch, num_epochs):
+        if hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
+        model.train()
+
+        def log_step(i, ld, epoch=epoch):
+            if use_wandb and rank == 0 and wandb_instance is not None and i % log_interval == 0:
+                wandb_instance.log({"train/total_loss": ld["total_loss"], "train/box_loss": ld["box_loss"],
+                                    "train/cls_loss": ld["cls_loss"], "step": epoch * len(train_loader) + i})
+
+        tr = _run_epoch(model, train_loader, criterion, device, autocast_kw, rank,
+                        f"[Epoch {epoch + 1}/{num_epochs}] Training", optimizer, scaler, on_step=log_step)
+        if rank != -1:
+            tr = reduce_values(tr, average=True)
+
+        model.eval()
+        metrics.reset()
+        with torch.no_grad():
+            va = _run_epoch(model, val_loader, criterion, device, autocast_kw, rank,
+                            f"[Epoch {epoch + 1}/{num_epochs}] Validation", metrics=metrics,
+                            conf_threshold=conf_threshold, num_classes=num_classes)
+        va = reduce_values(va, average=True)
+        md = metrics.compute()
+        scheduler.step(va[0])
+
+        if rank == 0:
+            if use_wandb and wandb_instance:
+                wandb_instance.log({"epoch": epoch + 1, "train/epoch_loss": tr[0], "train/epoch_box_loss": tr[1],
+                                    "train/epoch_cls_loss": tr[2], "val/epoch_loss": va[0], "val/epoch_box_loss": va[1],
+                                    "val/epoch_cls_loss": va[2], "val/precision": md["precision"],
+                                    "val/recall": md["recall"], "val/f1_score": md["f1_score"], "val/mAP": md["mAP"],
+                                    "lr": optimizer.param_groups[0]["lr"]})
+            save_checkpoint(model, optimizer, epoch + 1, va[0], checkpoint_dir=checkpoint_dir)
+            w = tqdm.write
+            w("=" * 80)
+            w(f"Epoch {epoch + 1}/{num_epochs} Summary:")
+            w(f"  Train - Total: {tr[0]:.4f} | Box: {tr[1]:.4f} | Cls: {tr[2]:.4f}")
+            w(f"  Val   - Total: {va[0]:.4f} | Box: {va[1]:.4f} | Cls: {va[2]:.4f}")
+            w(f"  Metrics - Precision: {md['precision']:.4f} | Recall: {md['recall']:.4f} | F1: {md['f1_score']:.4f} | mAP: {md['mAP']:.4f}")
+            w(f"  Detection - TP: {md['true_positives']} | FP: {md['false_positives']} | FN: {md['false_negatives']}")
+            w(f"  LR: {optimizer.param_groups[0]['lr']:.6f}")
+            w("=" * 80 + "\n")

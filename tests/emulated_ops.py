@@ -262,3 +262,11 @@ def install(monkeypatch):
     me = sys.modules[__name__]
     for name in LEAVES:
         monkeypatch.setattr(real, name, getattr(me, name))
+
+
+def install_plain():
+    """Same swap without pytest (spawned worker processes)."""
+    import sys
+    me = sys.modules[__name__]
+    for name in LEAVES:
+        setattr(real, name, getattr(me, name))
