@@ -215,6 +215,9 @@ __global__ void k_dw3x3_wgrad(const T* __restrict__ x, int ldx, const T* __restr
             }
         }
     }
+    // per-slab partial sums (no atomics: 9*C addresses would each take one add per slab, the contended
+    // regime of the global-atomic unit); k_dw_wgrad_finalize sums the slabs
+    float* part = dw + (long)blockIdx.x * C * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
@@ -226,9 +229,26 @@ __global__ void k_dw3x3_wgrad(const T* __restrict__ x, int ldx, const T* __restr
             for (int j = 0; j < V; ++j) {
                 float s = 0.f;
                 for (int rr = 0; rr < rpb; ++rr) s += red[threadIdx.x + rr * tpr][j];
-                atomicAdd(dw + (long)(cg * V + j) * 9 + t, s);
+                part[(long)(cg * V + j) * 9 + t] = s;
             }
         }
+    }
+}
+
+// out[e] = sum_b part[b][e]; (32 elements x 32 parts) per 1024-thread workgroup
+__global__ void k_dw_wgrad_finalize(const float* __restrict__ part, int nslab, int E, float* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int el = threadIdx.x & 31, pj = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    float s = 0.f;
+    if (e < E)
+        for (int b = pj; b < nslab; b += 32) s += part[(long)b * E + e];
+    red[pj][el] = s;
+    __syncthreads();
+    if (pj == 0 && e < E) {
+        float t = 0.f;
+        for (int j = 0; j < 32; ++j) t += red[j][el];
+        out[e] = t;
     }
 }
 
@@ -442,27 +462,33 @@ int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int
     return dw_launch<true>(dy, lddy, w, dx, lddx, N, H, W, C, dtype, st);
 }
 
-// dw fp32 [C][9], zeroed here
-int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, int N, int H, int W, int C,
-                         int dtype, hipStream_t st) {
-    int rc = hip_status(hipMemsetAsync(dw, 0, (size_t)C * 9 * sizeof(float), st));
-    if (rc) return rc;
+// number of row slabs (= partial blocks) yolo_dwconv3x3_wgrad uses for an (N, H) map
+int yolo_dw_wgrad_nslab(int N, int H) {
     int nrows = N * H;
     int slabs = nrows < 1024 ? nrows : 1024;
     int rps = (nrows + slabs - 1) / slabs;
-    slabs = (nrows + rps - 1) / rps;
+    return (nrows + rps - 1) / rps;
+}
+
+// dw fp32 [C][9]; partial: fp32 scratch [nslab][C][9]
+int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* partial, int N, int H,
+                         int W, int C, int dtype, hipStream_t st) {
+    int nrows = N * H;
+    int slabs = yolo_dw_wgrad_nslab(N, H);
+    int rps = (nrows + slabs - 1) / slabs;
     YOLO_DISPATCH_T(dtype, {
         if (vecok<T>(x, ldx, C) && vecok<T>(dy, ldy, C)) {
             constexpr int V = vec_of<T>::N;
             int cv = C / V, tpr = cv < 256 ? cv : 256;
             hipLaunchKernelGGL((k_dw3x3_wgrad<T, V>), dim3(slabs, ceil_div(cv, tpr)), dim3(256), 0, st, (const T*)x, ldx,
-                               (const T*)dy, ldy, dw, N, H, W, C, rps);
+                               (const T*)dy, ldy, partial, N, H, W, C, rps);
         } else {
             int tpr = C < 256 ? C : 256;
             hipLaunchKernelGGL((k_dw3x3_wgrad<T, 1>), dim3(slabs, ceil_div(C, tpr)), dim3(256), 0, st, (const T*)x, ldx,
-                               (const T*)dy, ldy, dw, N, H, W, C, rps);
+                               (const T*)dy, ldy, partial, N, H, W, C, rps);
         }
     });
+    hipLaunchKernelGGL(k_dw_wgrad_finalize, dim3(ceil_div(C * 9, 32)), dim3(1024), 0, st, partial, slabs, C * 9, dw);
     return YOLO_LAUNCH_CHECK();
 }
 

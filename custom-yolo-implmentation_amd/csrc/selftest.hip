@@ -1,0 +1,28 @@
+// Hardware self-tests of instruction semantics the tiled kernels rely on (run by tests/test_gpu_selftest.py).
+#include "common.h"
+
+namespace {
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// LDS tile T[32 rows][16 cols] of 16-bit values.  Lane l (g = l>>4, i = l&15) issues two
+// ds_read_b64_tr_b16 with addresses &T[8g + (i>>2)][4*(i&3)] and &T[8g + 4 + (i>>2)][4*(i&3)].
+// Expected (guide T10): out[l][q] = T[8g + q][i], out[l][4+q] = T[8g + 4 + q][i].
+__global__ void k_selftest_tr16(const short* __restrict__ in, short* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) short T[32 * 16];
+    const int l = threadIdx.x;
+    for (int e = l; e < 32 * 16; e += 64) T[e] = in[e];
+    __syncthreads();
+    const int g = l >> 4, i = l & 15;
+    const short* a1 = &T[(8 * g + (i >> 2)) * 16 + 4 * (i & 3)];
+    const short* a2 = &T[(8 * g + 4 + (i >> 2)) * 16 + 4 * (i & 3)];
+    s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    s16x4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { out[l * 8 + q] = r1[q]; out[l * 8 + 4 + q] = r2[q]; }
+}
+}  // namespace
+
+extern "C" int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_selftest_tr16, dim3(1), dim3(64), 0, st, (const short*)tile_in, (short*)out);
+    return YOLO_LAUNCH_CHECK();
+}

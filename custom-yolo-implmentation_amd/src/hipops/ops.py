@@ -199,7 +199,8 @@ def dw_wgrad(x, dy):
     n, c, h, w, ldx = geom(x)
     _, _, _, _, ldy = geom(dy)
     dw = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=x.device)
-    lib.call("yolo_dwconv3x3_wgrad", _p(x), ldx, _p(dy), ldy, _p(dw), n, h, w, c, dt(x), _stream(x))
+    part = torch.empty(lib.query("yolo_dw_wgrad_nslab", n, h) * c * 9, dtype=torch.float32, device=x.device)
+    lib.call("yolo_dwconv3x3_wgrad", _p(x), ldx, _p(dy), ldy, _p(dw), _p(part), n, h, w, c, dt(x), _stream(x))
     return dw
 
 

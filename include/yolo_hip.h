@@ -60,7 +60,8 @@ int yolo_stem_unpack_wgrad(const float* dw32, int Cout, void* dw, int dw_dtype, 
 /* depthwise 3x3 (groups == channels: model_blocks.py:183, head.py:56,58) */
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype, hipStream_t st);
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int dtype, hipStream_t st);
-int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, int N, int H, int W, int C, int dtype, hipStream_t st);
+int yolo_dw_wgrad_nslab(int N, int H);
+int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* partial, int N, int H, int W, int C, int dtype, hipStream_t st);
 
 /* ---- BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU/Identity + residual add (model_blocks.py:28-34,62,223-224) */
 int yolo_reduce_nblk(long npix, int C);
@@ -93,6 +94,9 @@ int yolo_dfl_expect(const void* x, void* y, int B, int A, int dtype, hipStream_t
 int yolo_nms_capacity(int M, int nc, int multi_label);
 size_t yolo_nms_workspace_bytes(int bs, int M, int nc, int multi_label);
 int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, float iou_thres, const int* classes, int n_classes, int agnostic, int multi_label, int max_det, float* out, int* out_count, int* status, void* workspace, hipStream_t st);
+
+/* ---- hardware self-tests (instruction semantics the tiled kernels assume; tests/test_gpu_selftest.py; no reference counterpart: model_blocks.py:1) */
+int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st);
 
 #ifdef __cplusplus
 }
