@@ -6,6 +6,7 @@
 // online softmax; lse saved for the backward, which recomputes P (two kernels, no atomics:
 // A = dQ and D=rowsum(dO*O) per query block, B = dK/dV per key block).
 #include "common.h"
+#include "gemm.h"
 
 namespace {
 
@@ -281,43 +282,212 @@ template <typename F> int allow_lds(F* fn, size_t bytes) {
     return hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 / f16 path: the matmuls run on the matrix cores through the batched GEMM (gemm.h); P is
+// materialised ([N*heads][T][Tp], Tp = T rounded up to 32, pad columns zero) and kept for the backward.
+// ------------------------------------------------------------------------------------------------
+// P = softmax(S) row by row; one wave per row
+template <typename T>
+__global__ void k_softmax_rows(const float* __restrict__ S, T* __restrict__ P, long rows, int Tn, int Tp) {
+    const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* s = S + r * Tp;
+    float mx = -INFINITY;
+    for (int j = lane; j < Tn; j += 64) mx = fmaxf(mx, s[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Tn; j += 64) sum += __expf(s[j] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    T* p = P + r * Tp;
+    for (int j = lane; j < Tp; j += 64) p[j] = from_f<T>(j < Tn ? __expf(s[j] - mx) * inv : 0.f);
+}
+
+// dS = P * (dP - rowsum(P*dP)); one wave per row
+template <typename T>
+__global__ void k_softmax_bwd_rows(const T* __restrict__ P, const float* __restrict__ dP, T* __restrict__ dS, long rows,
+                                   int Tn, int Tp) {
+    const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const T* p = P + r * Tp;
+    const float* g = dP + r * Tp;
+    float d = 0.f;
+    for (int j = lane; j < Tn; j += 64) d += to_f<T>(p[j]) * g[j];
+    d = wave_sum(d);
+    T* o = dS + r * Tp;
+    for (int j = lane; j < Tp; j += 64) o[j] = from_f<T>(j < Tn ? to_f<T>(p[j]) * (g[j] - d) : 0.f);
+}
+
+// dst[p][h*dgs + doff + d] = src[p][h*sgs + soff + d], d < width (16-byte packets)
+template <typename T>
+__global__ void k_group_copy(const T* __restrict__ src, int lds_, int sgs, int soff, T* __restrict__ dst, int ldd, int dgs,
+                             int doff, long npix, int heads, int width) {
+    constexpr int V = vec_of<T>::N;
+    const int per = heads * (width / V);
+    long total = npix * per;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / per;
+        int e = (int)(i - p * per);
+        int h = e / (width / V), d = (e - h * (width / V)) * V;
+        *reinterpret_cast<uint4*>(dst + p * ldd + h * dgs + doff + d) =
+            *reinterpret_cast<const uint4*>(src + p * lds_ + h * sgs + soff + d);
+    }
+}
+
+inline int round32(int t) { return (t + 31) / 32 * 32; }
+
+template <typename T>
+int group_copy(const void* src, int lds_, int sgs, int soff, void* dst, int ldd, int dgs, int doff, long npix, int heads,
+               int width, hipStream_t st) {
+    long total = npix * heads * (width / vec_of<T>::N);
+    int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL((k_group_copy<T>), dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, (const T*)src, lds_, sgs, soff, (T*)dst,
+                       ldd, dgs, doff, npix, heads, width);
+    return YOLO_LAUNCH_CHECK();
+}
+
+GemmOperand operand(const void* p, long b0, long b1, long rs, int kcontig) {
+    GemmOperand o;
+    o.p = p; o.b0 = b0; o.b1 = b1; o.rs = rs; o.kcontig = kcontig;
+    return o;
+}
+
+template <typename T>
+int attn_fwd_mfma(const T* qkv, int ldq, T* o, int ldo, T* vp, int ldv, T* P, float* S, int N, int Tn, int heads, int dk,
+                  int dh, float scale, int dtype, hipStream_t st) {
+    const int cq = 2 * dk + dh, Tp = round32(Tn);
+    const long pb1 = (long)Tn * Tp, pb0 = pb1 * heads;
+    GemmArgs g;
+    g.nb0 = N; g.nb1 = heads; g.accumulate = 0;
+    // S = scale * Q K^T
+    g.A = operand(qkv, (long)Tn * ldq, cq, ldq, 1);
+    g.B = operand(qkv + dk, (long)Tn * ldq, cq, ldq, 1);
+    g.C = S; g.c_b0 = pb0; g.c_b1 = pb1; g.c_rs = Tp; g.c_f32 = 1; g.alpha = scale;
+    g.M = Tn; g.N = Tn; g.K = dk; g.Kvalid = dk;
+    int rc = gemm_batched_launch(g, dtype, st);
+    if (rc) return rc;
+    const long rows = (long)N * heads * Tn;
+    hipLaunchKernelGGL((k_softmax_rows<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, rows, Tn, Tp);
+    // O = P V
+    g.A = operand(P, pb0, pb1, Tp, 1);
+    g.B = operand(qkv + 2 * dk, (long)Tn * ldq, cq, ldq, 0);
+    g.C = o; g.c_b0 = (long)Tn * ldo; g.c_b1 = dh; g.c_rs = ldo; g.c_f32 = 0; g.alpha = 1.f;
+    g.M = Tn; g.N = dh; g.K = Tp; g.Kvalid = Tn;
+    rc = gemm_batched_launch(g, dtype, st);
+    if (rc) return rc;
+    return group_copy<T>(qkv, ldq, cq, 2 * dk, vp, ldv, dh, 0, (long)N * Tn, heads, dh, st);
+}
+
+template <typename T>
+int attn_bwd_mfma(const T* qkv, int ldq, const T* d_o, int lddo, const T* d_vp, int lddv, const T* P, float* dP, T* dS,
+                  T* dqkv, int lddq, int N, int Tn, int heads, int dk, int dh, float scale, int dtype, hipStream_t st) {
+    const int cq = 2 * dk + dh, Tp = round32(Tn);
+    const long pb1 = (long)Tn * Tp, pb0 = pb1 * heads;
+    const long qb0 = (long)Tn * ldq, gb0 = (long)Tn * lddq, ob0 = (long)Tn * lddo;
+    GemmArgs g;
+    g.nb0 = N; g.nb1 = heads;
+    // dP = dO V^T
+    g.A = operand(d_o, ob0, dh, lddo, 1);
+    g.B = operand(qkv + 2 * dk, qb0, cq, ldq, 1);
+    g.C = dP; g.c_b0 = pb0; g.c_b1 = pb1; g.c_rs = Tp; g.c_f32 = 1; g.alpha = 1.f; g.accumulate = 0;
+    g.M = Tn; g.N = Tn; g.K = dh; g.Kvalid = dh;
+    int rc = gemm_batched_launch(g, dtype, st);
+    if (rc) return rc;
+    const long rows = (long)N * heads * Tn;
+    hipLaunchKernelGGL((k_softmax_bwd_rows<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, dS, rows, Tn, Tp);
+    // dV = P^T dO (+ d_vp, copied into the v slots first)
+    if (d_vp) {
+        rc = group_copy<T>(d_vp, lddv, dh, 0, dqkv, lddq, cq, 2 * dk, (long)N * Tn, heads, dh, st);
+        if (rc) return rc;
+    }
+    g.A = operand(P, pb0, pb1, Tp, 0);
+    g.B = operand(d_o, ob0, dh, lddo, 0);
+    g.C = dqkv + 2 * dk; g.c_b0 = gb0; g.c_b1 = cq; g.c_rs = lddq; g.c_f32 = 0; g.alpha = 1.f; g.accumulate = d_vp ? 1 : 0;
+    g.M = Tn; g.N = dh; g.K = Tp; g.Kvalid = Tn;
+    rc = gemm_batched_launch(g, dtype, st);
+    if (rc) return rc;
+    // dQ = scale * dS K
+    g.A = operand(dS, pb0, pb1, Tp, 1);
+    g.B = operand(qkv + dk, qb0, cq, ldq, 0);
+    g.C = dqkv; g.alpha = scale; g.accumulate = 0;
+    g.M = Tn; g.N = dk; g.K = Tp; g.Kvalid = Tn;
+    rc = gemm_batched_launch(g, dtype, st);
+    if (rc) return rc;
+    // dK = scale * dS^T Q
+    g.A = operand(dS, pb0, pb1, Tp, 0);
+    g.B = operand(qkv, qb0, cq, ldq, 0);
+    g.C = dqkv + dk;
+    return gemm_batched_launch(g, dtype, st);
+}
+
 }  // namespace
 
 extern "C" {
 
-// o, vp: (N, T, heads*dh); lse: fp32 [N][heads][T]
-int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, float* lse, int N, int T_, int heads,
-                  int dk, int dh, float scale, int dtype, hipStream_t st) {
+// bytes kept from forward to backward (fp32: row log-sum-exp; bf16/f16: the probability matrices)
+size_t yolo_attn_stash_bytes(int N, int T_, int heads, int dtype) {
+    if (dtype == YOLO_F32) return (size_t)N * heads * T_ * 4;
+    return (size_t)N * heads * T_ * round32(T_) * 2;
+}
+
+// scratch bytes (either direction)
+size_t yolo_attn_workspace_bytes(int N, int T_, int heads, int dtype) {
+    if (dtype == YOLO_F32) return (size_t)N * heads * T_ * 4;
+    return (size_t)N * heads * T_ * round32(T_) * 6;          // fp32 scores / dP + 16-bit dS
+}
+
+// o, vp: (N, T, heads*dh)
+int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, void* stash, void* ws, int N, int T_,
+                  int heads, int dk, int dh, float scale, int dtype, hipStream_t st) {
     if (!dims_ok(dk, dh)) return YOLO_ERR_ARG;
+    if (dtype != YOLO_F32) {
+        if (dk % 8 || dh % 8 || ldq % 8 || ldo % 4 || ldv % 8) return YOLO_ERR_ARG;
+        if (dtype == YOLO_BF16)
+            return attn_fwd_mfma<bf16_t>((const bf16_t*)qkv, ldq, (bf16_t*)o, ldo, (bf16_t*)vp, ldv, (bf16_t*)stash, (float*)ws, N,
+                                         T_, heads, dk, dh, scale, dtype, st);
+        return attn_fwd_mfma<f16_t>((const f16_t*)qkv, ldq, (f16_t*)o, ldo, (f16_t*)vp, ldv, (f16_t*)stash, (float*)ws, N, T_,
+                                    heads, dk, dh, scale, dtype, st);
+    }
     AttnDims a{N, T_, heads, dk, dh, ldq, ldo, ldv, scale};
     size_t smem = sizeof(float) * (size_t)(CH * (dk + 1) + CH * (dh + 1) + QB * (dk + 1) + 4 * CH);
     dim3 grid(ceil_div(T_, QB), heads, N);
-    YOLO_DISPATCH_T(dtype, {
-        int rc = allow_lds(k_attn_fwd<T>, smem);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_attn_fwd<T>), grid, dim3(256), smem, st, a, (const T*)qkv, (T*)o, (T*)vp, lse);
-    });
+    int rc = allow_lds(k_attn_fwd<float>, smem);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_fwd<float>), grid, dim3(256), smem, st, a, (const float*)qkv, (float*)o, (float*)vp, (float*)stash);
     return YOLO_LAUNCH_CHECK();
 }
 
-// dqkv (N, T, heads*(2dk+dh)) fully written; d_vp may be null; Dbuf: fp32 scratch [N][heads][T]
-int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp,
-                  int lddv, const float* lse, float* Dbuf, void* dqkv, int lddq, int N, int T_, int heads, int dk,
-                  int dh, float scale, int dtype, hipStream_t st) {
+// dqkv (N, T, heads*(2dk+dh)) fully written; d_vp may be null
+int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv,
+                  const void* stash, void* ws, void* dqkv, int lddq, int N, int T_, int heads, int dk, int dh, float scale,
+                  int dtype, hipStream_t st) {
     if (!dims_ok(dk, dh)) return YOLO_ERR_ARG;
+    if (dtype != YOLO_F32) {
+        if (dk % 8 || dh % 8 || ldq % 8 || lddo % 8 || lddq % 4 || (d_vp && lddv % 8)) return YOLO_ERR_ARG;
+        const size_t n = (size_t)N * heads * T_ * round32(T_);
+        float* dP = (float*)ws;
+        void* dS = (char*)ws + n * 4;
+        if (dtype == YOLO_BF16)
+            return attn_bwd_mfma<bf16_t>((const bf16_t*)qkv, ldq, (const bf16_t*)d_o, lddo, (const bf16_t*)d_vp, lddv,
+                                         (const bf16_t*)stash, dP, (bf16_t*)dS, (bf16_t*)dqkv, lddq, N, T_, heads, dk, dh, scale,
+                                         dtype, st);
+        return attn_bwd_mfma<f16_t>((const f16_t*)qkv, ldq, (const f16_t*)d_o, lddo, (const f16_t*)d_vp, lddv,
+                                    (const f16_t*)stash, dP, (f16_t*)dS, (f16_t*)dqkv, lddq, N, T_, heads, dk, dh, scale, dtype, st);
+    }
     AttnDims a{N, T_, heads, dk, dh, ldq, ldo, 0, scale};
     size_t smA = sizeof(float) * (size_t)(CH * (dk + 1) + CH * (dh + 1) + QB * (dk + 1) + QB * (dh + 1) + 4 * CH);
     size_t smB = sizeof(float) * (size_t)(CH * (dk + 1) + CH * (dh + 1) + QB * (dk + 1) + QB * (dh + 1) + 2 * CH + 8 * CH);
     dim3 grid(ceil_div(T_, QB), heads, N);
-    YOLO_DISPATCH_T(dtype, {
-        int rc = allow_lds(k_attn_bwd_q<T>, smA);
-        if (!rc) rc = allow_lds(k_attn_bwd_kv<T>, smB);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_attn_bwd_q<T>), grid, dim3(256), smA, st, a, (const T*)qkv, (const T*)o, (const T*)d_o, lddo,
-                           lse, Dbuf, (T*)dqkv, lddq);
-        hipLaunchKernelGGL((k_attn_bwd_kv<T>), grid, dim3(256), smB, st, a, (const T*)qkv, (const T*)d_o, lddo,
-                           (const T*)d_vp, lddv, lse, Dbuf, (T*)dqkv, lddq);
-    });
+    int rc = allow_lds(k_attn_bwd_q<float>, smA);
+    if (!rc) rc = allow_lds(k_attn_bwd_kv<float>, smB);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_bwd_q<float>), grid, dim3(256), smA, st, a, (const float*)qkv, (const float*)o, (const float*)d_o,
+                       lddo, (const float*)stash, (float*)ws, (float*)dqkv, lddq);
+    hipLaunchKernelGGL((k_attn_bwd_kv<float>), grid, dim3(256), smB, st, a, (const float*)qkv, (const float*)d_o, lddo,
+                       (const float*)d_vp, lddv, (const float*)stash, (const float*)ws, (float*)dqkv, lddq);
     return YOLO_LAUNCH_CHECK();
 }
 

@@ -9,6 +9,8 @@ int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst,
                      int accumulate, int dtype, hipStream_t st);
 int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const void* x, const void* dy);
+int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W,
+                       int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
 int mfma_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W,
                       int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
 
@@ -410,8 +412,11 @@ int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw
     int K = k * k * Cin, Kpad = round_up32(K);
     int rc = hip_status(hipMemsetAsync(dwp, 0, (size_t)Cout * Kpad * sizeof(float), st));
     if (rc) return rc;
-    if (algo != 1 && mfma_wgrad_eligible(Cin, Cout, ldx, ldy, dtype, x, dy))
-        return mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+    if (algo != 1 && mfma_wgrad_eligible(Cin, Cout, ldx, ldy, dtype, x, dy)) {
+        if (algo == 3)   // first design (per-tap workgroups, LDS-transposed tiles), kept for A/B runs
+            return mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+        return mfma_wgrad2_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+    }
     if (algo == 2) return YOLO_ERR_ARG;
     long nrows = (long)N * OH;
     long elems = (long)Cout * K;

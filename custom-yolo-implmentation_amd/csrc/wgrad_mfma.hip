@@ -1,0 +1,203 @@
+// Weight gradient of a dense conv on the matrix cores, second design.
+//   dW[co][tap][ci] = sum over output pixels p of dY[p][co] * X[p*s + tap - pad][ci]
+// The reduction index is the pixel.  One workgroup owns a (32*TCO x 32*TCI) block of (co, ci) for ALL
+// k*k taps and walks a slab of 4x8 output-pixel patches: per patch it stages dY (32 pixels) and the X
+// patch with its halo ((3s+k) x (7s+k) pixels) ONCE, in their natural [pixel][channel] layout, and
+// feeds the MFMAs through ds_read_b64_tr_b16 -- the hardware transposing read turns "pixel-major"
+// into the K-major fragment both operands need, at any pixel offset, so the 9 taps are 9 address
+// offsets into the same patch (a [channel][pixel] LDS image would need a misaligned read per tap).
+// MFMA k index j <-> patch pixel (row j/8, col j%8): lane group g = patch row g.
+// Slabs are combined with fp32 atomics into the packed gradient matrix (64-byte runs along ci).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+template <typename T> struct mm;
+template <> struct mm<bf16_t> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct mm<f16_t> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int LDC = 72;      // LDS row (one pixel): 64 channels + 8 pad, 144 bytes
+
+struct WgArgs {
+    int N, H, W, Cin, ldx, OH, OW, Cout, ldy, Kpad;
+    int pbh, pbw;            // patches per image along h / w
+    long npatch, per_slab;
+};
+
+// two transposing reads -> one MFMA fragment: element j = LDS[(row0 + (j&3) + 4*(j>>2)*rstep ... )]
+template <typename T>
+__device__ __forceinline__ typename mm<T>::frag tr_frag(const T* p_lo, const T* p_hi) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_lo);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_hi);
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename mm<T>::frag, both);
+}
+
+template <typename T, int KS, int S, int TCO, int TCI>
+__global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ x, const T* __restrict__ dy,
+                                                float* __restrict__ dwp) {
+    constexpr int PAD = KS / 2;
+    constexpr int PH = 3 * S + KS, PW = 7 * S + KS;          // X patch (with halo) for 4 x 8 outputs
+    constexpr int XCH = PH * PW * 8;                          // 16-byte chunks in the X patch (64 channels)
+    constexpr int XR = (XCH + 255) / 256;                     // chunks per thread
+    constexpr int NT = KS * KS;
+    __shared__ __attribute__((aligned(16))) T ys[32 * LDC];
+    __shared__ __attribute__((aligned(16))) T xs[PH * PW * LDC];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wi = wave & 1;
+    // block tile = (2 waves x TCO x 16) co  x  (2 waves x TCI x 16) ci
+    const int bco = blockIdx.x * (32 * TCO), bci = blockIdx.y * (32 * TCI);
+    long p_begin = (long)blockIdx.z * a.per_slab, p_end = p_begin + a.per_slab;
+    if (p_end > a.npatch) p_end = a.npatch;
+
+    f32x4 acc[NT][TCO][TCI];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TCI; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // loader roles: dY: pixel j = tid>>3 (0..31), channel chunk tid&7;  X: chunk ids tid + 256*r
+    uint4 ry, rx[XR];
+    auto gload = [&](long pi) {
+        const int per_img = a.pbh * a.pbw;
+        const long n = pi / per_img;
+        const int rem = (int)(pi - n * per_img);
+        const int bh = rem / a.pbw, bw = rem - bh * a.pbw;
+        const int oh0 = bh * 4, ow0 = bw * 8;
+        {
+            const int j = tid >> 3, ch = (tid & 7) * 8;
+            const int oh = oh0 + (j >> 3), ow = ow0 + (j & 7);
+            ry = make_uint4(0, 0, 0, 0);
+            if (oh < a.OH && ow < a.OW && bco + ch < a.Cout)
+                ry = *reinterpret_cast<const uint4*>(dy + ((n * a.OH + oh) * (long)a.OW + ow) * a.ldy + bco + ch);
+        }
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int id = tid + 256 * r;
+            rx[r] = make_uint4(0, 0, 0, 0);
+            if (id < XCH) {
+                const int px = id >> 3, ch = (id & 7) * 8;
+                const int pr = px / PW, pc = px - pr * PW;
+                const int ih = oh0 * S - PAD + pr, iw = ow0 * S - PAD + pc;
+                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && bci + ch < a.Cin)
+                    rx[r] = *reinterpret_cast<const uint4*>(x + ((n * a.H + ih) * (long)a.W + iw) * a.ldx + bci + ch);
+            }
+        }
+    };
+    auto lstore = [&]() {
+        *reinterpret_cast<uint4*>(ys + (tid >> 3) * LDC + (tid & 7) * 8) = ry;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int id = tid + 256 * r;
+            if (id < XCH) *reinterpret_cast<uint4*>(xs + (id >> 3) * LDC + (id & 7) * 8) = rx[r];
+        }
+    };
+
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
+    if (p_begin < p_end) gload(p_begin);
+    for (long pi = p_begin; pi < p_end; ++pi) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (pi + 1 < p_end) gload(pi + 1);
+        // A fragments (dY^T): rows = co, k = patch pixel 8g + j  ->  LDS pixel rows 8g+q and 8g+4+q
+        typename mm<T>::frag fa[TCO];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const T* p = ys + (8 * g + q) * LDC + (wc * TCO + i) * 16 + c4;
+            fa[i] = tr_frag<T>(p, p + 4 * LDC);
+        }
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                // output pixel (row g, col q | q+4) reads X patch pixel (g*S + kh, col*S + kw)
+                const T* base = xs + ((g * S + kh) * PW + q * S + kw) * LDC + c4;
+#pragma unroll
+                for (int j = 0; j < TCI; ++j) {
+                    const T* p = base + (wi * TCI + j) * 16;
+                    typename mm<T>::frag fb = tr_frag<T>(p, p + 4 * S * LDC);
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i) acc[kh * KS + kw][i][j] = mm<T>::mma(fa[i], fb, acc[kh * KS + kw][i][j]);
+                }
+            }
+    }
+    // D rows = co ((lane>>4)*4 + r), cols = ci (lane & 15)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TCI; ++j) {
+                const int ci = bci + (wi * TCI + j) * 16 + i16;
+                if (ci >= a.Cin) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = bco + (wc * TCO + i) * 16 + g * 4 + r;
+                    if (co < a.Cout) atomicAdd(dwp + (long)co * a.Kpad + t * a.Cin + ci, acc[t][i][j][r]);
+                }
+            }
+}
+
+template <typename T, int KS, int S, int TCO, int TCI>
+void launch(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStream_t st) {
+    const int cot = (a.Cout + 32 * TCO - 1) / (32 * TCO), cit = (a.Cin + 32 * TCI - 1) / (32 * TCI);
+    WgArgs b = a;
+    // each workgroup ends with KS*KS*(32*TCO)*(32*TCI) fp32 atomics (147 KB for a 3x3 64x64 tile): keep the
+    // workgroup count at ~2 per CU for 3x3 so that flush stays far below the pixel traffic
+    long want = (KS == 3 ? 512 : 2048) / ((long)cot * cit);
+    if (want < 1) want = 1;
+    if (want > a.npatch) want = a.npatch;
+    b.per_slab = (a.npatch + want - 1) / want;
+    const int nslab = (int)((a.npatch + b.per_slab - 1) / b.per_slab);
+    hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI>), dim3(cot, cit, nslab), dim3(256), 0, st, b, (const T*)x, (const T*)dy, dwp);
+}
+
+template <typename T, int KS, int S>
+void launch_tiles(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStream_t st) {
+    const bool bigo = a.Cout > 32, bigi = a.Cin > 32;
+    if (bigo && bigi) launch<T, KS, S, 2, 2>(a, x, dy, dwp, st);
+    else if (bigo) launch<T, KS, S, 2, 1>(a, x, dy, dwp, st);
+    else if (bigi) launch<T, KS, S, 1, 2>(a, x, dy, dwp, st);
+    else launch<T, KS, S, 1, 1>(a, x, dy, dwp, st);
+}
+
+template <typename T>
+int launch_ks(const WgArgs& a, int k, int stride, const void* x, const void* dy, float* dwp, hipStream_t st) {
+    if (k == 1 && stride == 1) launch_tiles<T, 1, 1>(a, x, dy, dwp, st);
+    else if (k == 3 && stride == 1) launch_tiles<T, 3, 1>(a, x, dy, dwp, st);
+    else if (k == 3 && stride == 2) launch_tiles<T, 3, 2>(a, x, dy, dwp, st);
+    else return YOLO_ERR_ARG;
+    return YOLO_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+// dwp (zeroed by the caller) += packed gradient; same eligibility as the first design (mfma_wgrad_eligible)
+int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W, int Cin,
+                       int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st) {
+    WgArgs a;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.OH = OH; a.OW = OW; a.Cout = Cout; a.ldy = ldy; a.Kpad = Kpad;
+    a.pbh = (OH + 3) / 4; a.pbw = (OW + 7) / 8;
+    a.npatch = (long)N * a.pbh * a.pbw;
+    a.per_slab = 0;
+    if (a.npatch == 0) return YOLO_OK;
+    if (dtype == YOLO_BF16) return launch_ks<bf16_t>(a, k, stride, x, dy, dwp, st);
+    if (dtype == YOLO_F16) return launch_ks<f16_t>(a, k, stride, x, dy, dwp, st);
+    return YOLO_ERR_DTYPE;
+}

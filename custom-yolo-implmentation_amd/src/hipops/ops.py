@@ -149,6 +149,8 @@ def conv_wgrad(x, dy, k, stride, w_dtype):
     dwp = torch.empty(cout * kpad, dtype=torch.float32, device=x.device)
     lib.call("yolo_conv2d_wgrad", _p(x), ldx, _p(dy), ldy, _p(dwp), n, h, w, cin, oh, ow, cout, k, stride, dt(x),
              ALGO, _stream(x))
+    if k == 1 and kpad == cin and w_dtype == torch.float32:
+        return dwp.view(cout, cin, 1, 1)            # packed [Cout][Cin] IS the OIHW layout: no unpack pass
     dw = torch.empty((cout, cin, k, k), dtype=w_dtype, device=x.device)
     lib.call("yolo_conv_unpack_wgrad", _p(dwp), cout, cin, k, _p(dw), dt(w_dtype), _stream(x))
     return dw
@@ -251,8 +253,9 @@ def bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act):
     st = _stream(y)
     lib.call("yolo_bn_act_bwd_reduce", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), _p(mean), _p(invstd), npix, c,
              int(act), dt(y), _p(part), nblk, st)
-    buf = _f32(5 * c, y.device)
-    dgamma, dbeta, coef = buf[:c], buf[c:2 * c], buf[2 * c:]
+    # dgamma / dbeta are returned to autograd: standalone tensors (a slice of a bigger buffer cannot be taken
+    # over by AccumulateGrad and would be cloned with an extra copy kernel per parameter)
+    dgamma, dbeta, coef = _f32(c, y.device), _f32(c, y.device), _f32(3 * c, y.device)
     lib.call("yolo_bn_bwd_finalize", _p(part), nblk, npix, c, _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta),
              _p(coef), st)
     dy = new_nhwc(n, c, h, w, y.dtype, y.device)
@@ -314,23 +317,25 @@ def upsample2x_bwd(dout):
 
 # ------------------------------------------------------------------------------------------------ attention
 def attn_fwd(qkv, heads, dk, dh, scale):
+    """-> (o, vp, stash); stash = what the backward needs (fp32: row log-sum-exp, 16-bit: probabilities)."""
     n, cq, h, w, ld = geom(qkv)
     t = h * w
     o = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
     vp = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
-    lse = _f32(n * heads * t, qkv.device)
-    lib.call("yolo_attn_fwd", _p(qkv), ld, _p(o), heads * dh, _p(vp), heads * dh, _p(lse), n, t, heads, dk, dh,
+    stash = torch.empty(lib.query("yolo_attn_stash_bytes", n, t, heads, dt(qkv)), dtype=torch.uint8, device=qkv.device)
+    ws = torch.empty(lib.query("yolo_attn_workspace_bytes", n, t, heads, dt(qkv)), dtype=torch.uint8, device=qkv.device)
+    lib.call("yolo_attn_fwd", _p(qkv), ld, _p(o), heads * dh, _p(vp), heads * dh, _p(stash), _p(ws), n, t, heads, dk, dh,
              float(scale), dt(qkv), _stream(qkv))
-    return o, vp, lse
+    return o, vp, stash
 
 
-def attn_bwd(qkv, o, d_o, d_vp, lse, heads, dk, dh, scale):
+def attn_bwd(qkv, o, d_o, d_vp, stash, heads, dk, dh, scale):
     n, cq, h, w, ld = geom(qkv)
     t = h * w
     dqkv = new_nhwc(n, cq, h, w, qkv.dtype, qkv.device)
-    dbuf = _f32(n * heads * t, qkv.device)
+    ws = torch.empty(lib.query("yolo_attn_workspace_bytes", n, t, heads, dt(qkv)), dtype=torch.uint8, device=qkv.device)
     lib.call("yolo_attn_bwd", _p(qkv), ld, _p(o), geom(o)[4], _p(d_o), geom(d_o)[4], _p(d_vp),
-             geom(d_vp)[4] if d_vp is not None else 0, _p(lse), _p(dbuf), _p(dqkv), cq, n, t, heads, dk, dh,
+             geom(d_vp)[4] if d_vp is not None else 0, _p(stash), _p(ws), _p(dqkv), cq, n, t, heads, dk, dh,
              float(scale), dt(qkv), _stream(qkv))
     return dqkv
 

@@ -35,10 +35,11 @@ class Conv(nn.Module):
         self.norm = nn.BatchNorm2d(out_ch, eps=0.001, momentum=0.03)
         self.relu = activation
         self._k, self._s, self._dw, self._act = k, s, g != 1, _act_code(activation)
+        self._count_batches = True      # a parent Model bumps all counters in one multi-tensor op instead
 
     def forward(self, x, residual=None):
         n = self.norm
-        if self.training:
+        if self.training and self._count_batches:
             n.num_batches_tracked.add_(1)
         return F_.ConvBnAct.apply(x, self.conv.weight, n.weight, n.bias, residual, (n.running_mean, n.running_var),
                                   self._k, self._s, self._dw, self._act, self.training, n.momentum, n.eps)

@@ -81,8 +81,10 @@ int yolo_upsample2x_fwd(const void* x, int ldx, void* out, int ldo, int N, int H
 int yolo_upsample2x_bwd(const void* dout, int ldd, void* dx, int ldx, int N, int H, int W, int C, int accumulate, int dtype, hipStream_t st);
 
 /* ---- PSA attention core (model_blocks.py:186-197) */
-int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, float* lse, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
-int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv, const float* lse, float* Dbuf, void* dqkv, int lddq, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
+size_t yolo_attn_stash_bytes(int N, int T_, int heads, int dtype);
+size_t yolo_attn_workspace_bytes(int N, int T_, int heads, int dtype);
+int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, void* stash, void* ws, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
+int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv, const void* stash, void* ws, void* dqkv, int lddq, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
 
 /* ---- YoloDFLQFLoss forward+gradient (losses.py:93-281) */
 size_t yolo_loss_workspace_bytes(int N, int A, int G);

@@ -212,12 +212,14 @@ def test_attention(dtype, heads, dk, dh, h, w):
     n = 2
     qkv = nhwc(rnd(n, heads * (2 * dk + dh), h, w, seed=50).to(dtype))
     scale = dk ** -0.5
-    og, vg, lse = o.attn_fwd(dev(qkv), heads, dk, dh, scale)
+    og, vg, stash = o.attn_fwd(dev(qkv), heads, dk, dh, scale)
     o_ref, v_ref, lse_ref = emu.attn_fwd(qkv, heads, dk, dh, scale)
-    check(og, o_ref, dtype, "attn o"), check(lse, lse_ref, torch.float32, "lse", mult=4.0)
+    check(og, o_ref, dtype, "attn o", mult=2.0)
+    if dtype == torch.float32:          # fp32 path stashes the row log-sum-exp, 16-bit paths the probabilities
+        check(stash.view(torch.float32), lse_ref, torch.float32, "lse", mult=4.0)
     assert torch.equal(vg.cpu(), v_ref)
     d_o, d_v = nhwc(rnd(n, heads * dh, h, w, seed=51).to(dtype)), nhwc(rnd(n, heads * dh, h, w, seed=52).to(dtype))
-    dq = o.attn_bwd(dev(qkv), og, dev(d_o), dev(d_v), lse, heads, dk, dh, scale)
+    dq = o.attn_bwd(dev(qkv), og, dev(d_o), dev(d_v), stash, heads, dk, dh, scale)
     dq_ref = emu.attn_bwd(qkv, o_ref, d_o, d_v, lse_ref, heads, dk, dh, scale)
     check(dq, dq_ref, dtype, "attn dqkv", mult=4.0)
 
