@@ -61,15 +61,15 @@ class KernelTimer:
         setattr(self.ops, name, timed)
 
     def install(self):
-        def conv_flops(out, x, wp, bias, cout, k, stride):
+        def conv_flops(out, x, wp, bias, cout, k, stride, *_):
             n, _, oh, ow = out.shape
             return 2.0 * n * oh * ow * cout * x.shape[1] * k * k
 
-        def dgrad_flops(out, dy, wb, cin, h, w, k, stride):
+        def dgrad_flops(out, dy, wb, cin, h, w, k, stride, *_):
             n, cout, oh, ow = dy.shape
             return 2.0 * n * oh * ow * cout * cin * k * k
 
-        def wgrad_flops(out, x, dy, k, stride, wd):
+        def wgrad_flops(out, x, dy, k, stride, wd, *_):
             n, cout, oh, ow = dy.shape
             return 2.0 * n * oh * ow * cout * x.shape[1] * k * k
 
@@ -84,7 +84,7 @@ class KernelTimer:
         self._wrap("conv_fwd", "conv_mfma(fwd+dgrad)", conv_flops, io_bytes)
         self._wrap("conv_dgrad", "conv_mfma(fwd+dgrad)", dgrad_flops, io_bytes)
         self._wrap("conv_wgrad", "wgrad_mfma", wgrad_flops, io_bytes)
-        for nm in ("bn_train_stats", "bn_act_fwd", "bn_act_bwd", "copy_channels", "dw_fwd", "dw_dgrad", "dw_wgrad",
+        for nm in ("bn_stats_acc", "bn_finalize_acc", "bn_act_bwd", "bn_act_fwd", "copy_channels", "dw_fwd", "dw_dgrad", "dw_wgrad",
                    "maxpool5_fwd", "maxpool5_bwd", "upsample2x_fwd", "upsample2x_bwd", "head_pack", "head_unpack"):
             self._wrap(nm, "elementwise(bn/act/copy/pool)", None, io_bytes)
         self._wrap("attn_fwd", "attention", None, io_bytes)

@@ -4,6 +4,8 @@
 #include "common.h"
 #include "conv_geom.h"
 
+extern "C" int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int dtype, float* acc, hipStream_t st);
+
 // implemented in conv_mfma.hip
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst);
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst,
@@ -291,7 +293,10 @@ int run_conv(const ConvGeom& g, const void* src, const void* wm, const float* bi
     if (algo != 1 && mfma_conv_eligible(g, dtype, src, wm, dst))
         return mfma_conv_launch(g, src, wm, bias, dst, accumulate, dtype, st);
     if (algo == 2) return YOLO_ERR_ARG;   // MFMA demanded but the shape is not eligible
-    return launch_generic(g, src, wm, bias, dst, accumulate, dtype, st);
+    int rc = launch_generic(g, src, wm, bias, dst, accumulate, dtype, st);
+    if (rc == YOLO_OK && g.stats)         // the generic kernel has no statistics epilogue: one extra pass over y
+        rc = yolo_bn_stats_acc(dst, g.ldd, (long)g.N * g.Hd * g.Wd, g.Cd, dtype, g.stats, st);
+    return rc;
 }
 
 bool supported(int k, int stride) { return (k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)); }
@@ -357,12 +362,16 @@ int yolo_conv_unpack_wgrad(const float* dwp, int O, int I, int k, void* dw_oihw,
 
 // y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], w) (+ bias); pad = k/2; wp = forward-packed weights in `dtype`.
 // algo: 0 auto (MFMA when eligible), 1 generic VALU kernel, 2 MFMA or error.
-int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, int N, int H, int W,
-                    int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st) {
-    if (!supported(k, stride)) return YOLO_ERR_ARG;
+// stats_acc (optional, needs bias == null): fp32 [8][2][Cout], pre-zeroed; receives sum(y) and sum(y^2) per channel
+// (of the values as stored) for the BatchNorm that follows -- from the MFMA kernel's epilogue, no extra pass.
+int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N,
+                    int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo,
+                    hipStream_t st) {
+    if (!supported(k, stride) || (stats_acc && bias)) return YOLO_ERR_ARG;
     int pad = k / 2;
     if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return YOLO_ERR_ARG;
     ConvGeom g;
+    g.stats = stats_acc;
     g.N = N; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lds = ldx;
     g.Hd = OH; g.Wd = OW; g.Cd = Cout; g.ldd = ldy; g.Hg = OH; g.Wg = OW;
     g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = stride;
@@ -382,6 +391,7 @@ int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int ld
     long off = 0;
     for (int c = 0; c < ncls; ++c) {
         ConvGeom g;
+        g.stats = nullptr;
         g.N = N; g.Hs = OH; g.Ws = OW; g.Cs = Cout; g.lds = lddy;
         g.Hd = H; g.Wd = W; g.Cd = Cin; g.ldd = lddx;
         int kh[9], kw[9];

@@ -19,6 +19,7 @@ struct ConvGeom {
     int ntaps;
     int dh[9], dw[9];
     int K, Kpad;
+    float* stats;   // forward only: [8][2][Cd] fp32 accumulator for BatchNorm batch statistics, or null
 };
 
 static inline int round_up32(int k) { return (k + 31) / 32 * 32; }

@@ -43,6 +43,7 @@ constexpr int LDSROW = 40; // elements per LDS row (32 + 8 pad) = 80 bytes
 struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic indexing of kernargs)
     int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, Hg, Wg, ostep, ooff_h, ooff_w, sstride, ntaps, KT, Kpad;
     unsigned dh_pack, dw_pack;   // 2 bits per tap: value + 1
+    float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
 };
 
 // bijective XCD-aware remap (guide T1): blocks that share an XCD get a contiguous range of tiles
@@ -188,6 +189,49 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
             store_pack<T, 4>(drow + cbase, v);
         }
     }
+
+    // ---- optional: per-channel sum / sum of squares of the values just stored (rounded to T), added to
+    // replica (workgroup mod 8) of stats[8][2][Cd]: BatchNorm batch statistics without a second pass over y
+    float* const stats = g.stats;
+    if (stats != nullptr) {
+        float* sacc = reinterpret_cast<float*>(&lds_a[0][0][0]);          // [2][BN]; LDS is idle after the K loop
+        for (int t = tid; t < 2 * BN; t += 256) sacc[t] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = to_f<T>(from_f<T>(acc[i][j][r]));     // rows past the last pixel hold 0
+                    s[r] += v;
+                    q2[r] += v * v;
+                }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[r] += __shfl_xor(s[r], o, 64);
+                    q2[r] += __shfl_xor(q2[r], o, 64);
+                }
+            if (fr == 0) {
+                const int cl = crow + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(&sacc[cl + r], s[r]);
+                    atomicAdd(&sacc[BN + cl + r], q2[r]);
+                }
+            }
+        }
+        __syncthreads();
+        float* o = stats + (long)(blockIdx.x & 7) * 2 * g.Cd;
+        for (int t = tid; t < BN; t += 256)
+            if (cd0 + t < g.Cd) {
+                atomicAdd(o + cd0 + t, sacc[t]);
+                atomicAdd(o + g.Cd + cd0 + t, sacc[BN + t]);
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -291,6 +335,7 @@ GeomDev to_dev(const ConvGeom& g) {
     d.ldd = g.ldd; d.Hg = g.Hg; d.Wg = g.Wg; d.ostep = g.ostep; d.ooff_h = g.ooff_h; d.ooff_w = g.ooff_w;
     d.sstride = g.sstride; d.ntaps = g.ntaps; d.Kpad = g.Kpad; d.KT = g.Kpad / BK;
     d.dh_pack = d.dw_pack = 0;
+    d.stats = g.stats;
     for (int t = 0; t < g.ntaps; ++t) {
         d.dh_pack |= (unsigned)(g.dh[t] + 1) << (2 * t);
         d.dw_pack |= (unsigned)(g.dw[t] + 1) << (2 * t);

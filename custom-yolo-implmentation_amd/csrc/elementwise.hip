@@ -142,6 +142,236 @@ __global__ void k_channel_reduce(const T* __restrict__ y, int ldy, const T* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training-mode BN without finalize launches.  Per-channel sums live in a caller-zeroed accumulator
+// acc[BN_REPL][2][C] (fp32): producers (the conv epilogue, or k_channel_acc below) add their partial
+// sums into replica (workgroup index mod BN_REPL) with float atomics -- spreading a layer's adds over
+// 8 rows per channel keeps the global-atomic unit out of its contended regime -- and every consumer
+// workgroup folds the replicas and derives the per-channel constants for its own channel group in
+// its prologue.  Workgroup (0, y) also publishes mean / invstd / running statistics (forward) or
+// dgamma / dbeta (backward).
+// ---------------------------------------------------------------------------------------------
+constexpr int BN_REPL = 8;
+
+template <int V>
+__device__ __forceinline__ void fold_replicas(const float* __restrict__ acc, int C, int c0, float (&s)[V], float (&q)[V]) {
+    // issue every replica's loads before the first add: 16 independent packets per thread instead of a
+    // chain of dependent scalar loads (which cost ~14 us per launch)
+    float ts[BN_REPL][V], tq[BN_REPL][V];
+#pragma unroll
+    for (int r = 0; r < BN_REPL; ++r) {
+        const float* a = acc + (long)r * 2 * C + c0;
+        load_pack<float, V>(a, ts[r]);
+        load_pack<float, V>(a + C, tq[r]);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        s[j] = ((ts[0][j] + ts[1][j]) + (ts[2][j] + ts[3][j])) + ((ts[4][j] + ts[5][j]) + (ts[6][j] + ts[7][j]));
+        q[j] = ((tq[0][j] + tq[1][j]) + (tq[2][j] + tq[3][j])) + ((tq[4][j] + tq[5][j]) + (tq[6][j] + tq[7][j]));
+    }
+}
+
+// MODE 0: acc += (sum y, sum y^2).  MODE 1: acc += (sum dz, sum dz*yhat) with z = (y-mean)*invstd*gamma + beta
+template <typename T, int V, int MODE>
+__global__ void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                              long npix, int C, int act, float* __restrict__ acc) {
+    __shared__ float red[TPB][2 * V + 1];
+    const int cv = C / V;
+    const int tpr = cv < TPB ? cv : TPB;
+    const int rpb = TPB / tpr;
+    const int r = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    const bool active = (r < rpb) && (cg < cv);
+    float s[V], q[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
+    if (active) {
+        float sc[V], sh[V], mu[V], is[V];
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int c = cg * V + j;
+                mu[j] = mean[c]; is[j] = invstd[c];
+                sc[j] = gamma[c] * is[j]; sh[j] = beta[c] - mu[j] * sc[j];
+            }
+        }
+        for (long p = (long)blockIdx.x * rpb + r; p < npix; p += (long)gridDim.x * rpb) {
+            float a[V];
+            load_pack<T, V>(y + p * ldy + cg * V, a);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { s[j] += a[j]; q[j] += a[j] * a[j]; }
+            } else {
+                float d[V];
+                load_pack<T, V>(dout + p * ldd + cg * V, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float dz = d[j] * act_grad(a[j] * sc[j] + sh[j], act);
+                    s[j] += dz;
+                    q[j] += dz * ((a[j] - mu[j]) * is[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[threadIdx.x][j] = s[j]; red[threadIdx.x][V + j] = q[j]; }
+    __syncthreads();
+    if (r == 0 && cg < cv) {
+        for (int rr = 1; rr < rpb; ++rr) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s[j] += red[threadIdx.x + rr * tpr][j];
+                q[j] += red[threadIdx.x + rr * tpr][V + j];
+            }
+        }
+        float* o = acc + (long)(blockIdx.x % BN_REPL) * 2 * C;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { atomicAdd(o + cg * V + j, s[j]); atomicAdd(o + C + cg * V + j, q[j]); }
+    }
+}
+
+// acc[8][2][C] -> mean, invstd, scale, shift (+ running statistics): one thread per channel, 16 loads
+__global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, int C, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                  float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                  float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int r = 0; r < BN_REPL; ++r) { s += acc[(long)r * 2 * C + c]; q += acc[(long)r * 2 * C + C + c]; }
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = is;
+    const float g = gamma[c] * is;
+    scale[c] = g;
+    shift[c] = beta[c] - (float)m * g;
+    if (rmean) {
+        const double unb = count > 1.f ? var * (count / (count - 1.0)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// out = act(BN_batch(y)) (+ res), statistics taken from acc
+template <typename T, int V>
+__global__ void k_bn_act_fwd_train(const T* __restrict__ y, int ldy, const float* __restrict__ acc, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C,
+                                   int act) {
+    const int cv = C / V;
+    const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    const int r = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    if (r >= rpb || cg >= cv) return;
+    float s[V], q[V], sc[V], sh[V];
+    fold_replicas<V>(acc, C, cg * V, s, q);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cg * V + j;
+        const float m = s[j] / count;
+        float var = q[j] / count - m * m;
+        var = var < 0.f ? 0.f : var;
+        const float is = rsqrtf(var + eps);
+        sc[j] = gamma[c] * is;
+        sh[j] = beta[c] - m * sc[j];
+        if (blockIdx.x == 0 && r == 0) {
+            mean_out[c] = m;
+            invstd_out[c] = is;
+            if (rmean) {
+                const float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+            }
+        }
+    }
+    const long step = (long)gridDim.x * rpb;
+    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
+        const long p2 = p + step;
+        const bool two = p2 < npix;
+        float a[V], b[V];
+        load_pack<T, V>(y + p * ldy + cg * V, a);
+        if (two) load_pack<T, V>(y + p2 * ldy + cg * V, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], act);
+        if (res) {
+            float t[V];
+            load_pack<T, V>(res + p * ldr + cg * V, t);
+#pragma unroll
+            for (int j = 0; j < V; ++j) a[j] += t[j];
+        }
+        store_pack<T, V>(out + p * ldo + cg * V, a);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) b[j] = act_fwd(b[j] * sc[j] + sh[j], act);
+            if (res) {
+                float t[V];
+                load_pack<T, V>(res + p2 * ldr + cg * V, t);
+#pragma unroll
+                for (int j = 0; j < V; ++j) b[j] += t[j];
+            }
+            store_pack<T, V>(out + p2 * ldo + cg * V, b);
+        }
+    }
+}
+
+// dy = A*dz + B*y + D with the constants derived from acc = (sum dz, sum dz*yhat); block (0,y) writes dgamma/dbeta
+template <typename T, int V>
+__global__ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                         const float* __restrict__ acc, float count, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta, T* __restrict__ dy, int lddy, long npix, int C,
+                                         int act) {
+    const int cv = C / V;
+    const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    const int r = threadIdx.x / tpr;
+    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    if (r >= rpb || cg >= cv) return;
+    float s[V], q[V], sc[V], sh[V], cA[V], cB[V], cD[V];
+    fold_replicas<V>(acc, C, cg * V, s, q);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cg * V + j;
+        const float is = invstd[c], mu = mean[c], k0 = gamma[c] * is;
+        sc[j] = k0;
+        sh[j] = beta[c] - mu * k0;
+        const float c1 = s[j] / count, c2 = q[j] / count;
+        cA[j] = k0;
+        cB[j] = -k0 * c2 * is;
+        cD[j] = -k0 * c1 + k0 * c2 * mu * is;
+        if (blockIdx.x == 0 && r == 0) { dbeta[c] = s[j]; dgamma[c] = q[j]; }
+    }
+    const long step = (long)gridDim.x * rpb;
+    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
+        const long p2 = p + step;
+        const bool two = p2 < npix;
+        float a[V], d[V], a2[V], d2[V];
+        load_pack<T, V>(y + p * ldy + cg * V, a);
+        load_pack<T, V>(dout + p * ldd + cg * V, d);
+        if (two) {
+            load_pack<T, V>(y + p2 * ldy + cg * V, a2);
+            load_pack<T, V>(dout + p2 * ldd + cg * V, d2);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = cA[j] * (d[j] * act_grad(a[j] * sc[j] + sh[j], act)) + cB[j] * a[j] + cD[j];
+        store_pack<T, V>(dy + p * lddy + cg * V, d);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+                d2[j] = cA[j] * (d2[j] * act_grad(a2[j] * sc[j] + sh[j], act)) + cB[j] * a2[j] + cD[j];
+            store_pack<T, V>(dy + p2 * lddy + cg * V, d2);
+        }
+    }
+}
+
 // Finalize kernels run as (32 channels x 32 parts) 1024-thread workgroups: part j sums partial blocks
 // j, j+32, ... of its channel (128-byte coalesced rows), LDS combines the 32 parts; the thread with
 // part 0 gets the totals and returns its channel, the others return -1.  (A one-thread-per-channel
@@ -614,6 +844,77 @@ int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, con
             int cv = C / V;
             hipLaunchKernelGGL((k_bn_act_bwd_apply<T, V>), rs_grid(npix, cv), dim3(TPB), 0, st, (const T*)dout,
                                ldd, (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, npix, C, act);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+// ---- accumulator form (no finalize launches).  acc: fp32 [YOLO_BN_REPL = 8][2][C], zeroed by the caller.
+int yolo_bn_acc_elems(int C) { return BN_REPL * 2 * C; }
+
+static int launch_acc(int mode, const void* y, int ldy, const void* dout, int ldd, const float* gamma, const float* beta,
+                      const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* acc,
+                      hipStream_t st) {
+    int nblk = yolo_reduce_nblk(npix, C);
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(y, ldy, C) && (mode == 0 || vec_ok<T>(dout, ldd, C));
+        PICK_V(T, ok, {
+            int cv = C / V;
+            int tpr = cv < TPB ? cv : TPB;
+            dim3 g(nblk, ceil_div(cv, tpr));
+            if (mode == 0)
+                hipLaunchKernelGGL((k_channel_acc<T, V, 0>), g, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)nullptr, 0,
+                                   gamma, beta, mean, invstd, npix, C, act, acc);
+            else
+                hipLaunchKernelGGL((k_channel_acc<T, V, 1>), g, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)dout, ldd,
+                                   gamma, beta, mean, invstd, npix, C, act, acc);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int dtype, float* acc, hipStream_t st) {
+    return launch_acc(0, y, ldy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, npix, C, 0, dtype, acc, st);
+}
+
+int yolo_bn_finalize_acc(const float* acc, long count, int C, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                         float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_finalize_acc, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, (float)count, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                          const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype,
+                          hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(out, ldout, C) && (!res || vec_ok<T>(res, ldres, C));
+        PICK_V(T, ok, {
+            hipLaunchKernelGGL((k_bn_act_fwd_train<T, V>), rs_grid(npix, C / V), dim3(TPB), 0, st, (const T*)y, ldy, acc,
+                               (float)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                               (const T*)res, ldres, (T*)out, ldout, npix, C, act);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta,
+                           const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* acc,
+                           hipStream_t st) {
+    return launch_acc(1, y, ldy, dout, ldd, gamma, beta, mean, invstd, npix, C, act, dtype, acc, st);
+}
+
+int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta,
+                                const float* mean, const float* invstd, const float* acc, long count, float* dgamma,
+                                float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st) {
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(dout, ldd, C) && vec_ok<T>(dy, lddy, C);
+        PICK_V(T, ok, {
+            hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V>), rs_grid(npix, C / V), dim3(TPB), 0, st, (const T*)dout, ldd,
+                               (const T*)y, ldy, gamma, beta, mean, invstd, acc, (float)count, dgamma, dbeta, (T*)dy, lddy,
+                               npix, C, act);
         });
     });
     return YOLO_LAUNCH_CHECK();

@@ -30,52 +30,85 @@ def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
+class BnArena:
+    """Per-forward pool of zeroed BatchNorm accumulators: ONE memset covers every layer of a model pass.
+    A fresh pool per Model.forward keeps un-backpropagated passes independent (the autograd graph keeps
+    its pool alive); Conv blocks outside a Model allocate their own pair."""
+    current = None
+
+    def __init__(self, device, elems):
+        self.buf = ops.zero_(torch.empty(max(elems, 1), dtype=torch.float32, device=device))
+        self.off = 0
+
+    def take(self, c):
+        n = ops.BN_REPL * 2 * c
+        if self.off + n > self.buf.numel():
+            return None
+        acc = self.buf[self.off:self.off + n]
+        self.off += n
+        return acc
+
+    @staticmethod
+    def elems_for(channels):
+        return sum(ops.BN_REPL * 2 * c for c in channels)
+
+
 class ConvBnAct(torch.autograd.Function):
     """act(BN(conv(x))) (+ residual).  Reference: Conv.forward, src/model/model_blocks.py:31-34; the
     residual adds of Residual/PSABlock (:62, :223-224) ride in the same epilogue.
-    groups is 1 or C (depthwise 3x3)."""
+    groups is 1 or C (depthwise 3x3).  Training: the conv epilogue accumulates the batch statistics (no
+    separate pass over y); the backward uses the deterministic two-level reduction."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps):
         T = compute_dtype(x, weight)
         cout = weight.shape[0]
+        acc_f = None
+        if training:
+            acc_f = BnArena.current.take(cout) if BnArena.current is not None else None
+            if acc_f is None:
+                acc_f = ops.bn_acc_new(cout, x.device)
         # stem: a 3-channel image feeding a 3x3/2 conv is unfolded once (from NCHW directly) and then
         # runs as a 1x1 conv over K = 32 columns; x (saved for wgrad) becomes that column tensor
         stem = (not depthwise and weight.shape[1] == 3 and k == 3 and stride == 2 and not ctx.needs_input_grad[0])
         if stem:
             x = ops.stem_im2col(x, T)
-            y = ops.conv_fwd(x, ops.stem_pack_weights(weight, T), None, cout, 1, 1)
+            y = ops.conv_fwd(x, ops.stem_pack_weights(weight, T), None, cout, 1, 1, acc_f)
         elif depthwise:
             x = _as_nhwc(x, T)
-            w9 = _f32(weight).reshape(cout, 9)
-            y = ops.dw_fwd(x, w9)
+            y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9))
+            if training:
+                ops.bn_stats_acc(y, acc_f)
         else:
             x = _as_nhwc(x, T)
-            y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride)
+            y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride, acc_f)
         g32, b32 = _f32(gamma), _f32(beta)
         rm, rv = bufs
+        if res is not None:
+            res = _as_nhwc(res, T)
         if training:
             rm32, rv32 = _f32(rm), _f32(rv)
-            mean, invstd, scale, shift = ops.bn_train_stats(y, g32, b32, rm32, rv32, momentum, eps)
+            count = y.shape[0] * y.shape[2] * y.shape[3]
+            mean, invstd, scale, shift = ops.bn_finalize_acc(acc_f, count, g32, b32, rm32, rv32, momentum, eps)
             if rm32 is not rm:
                 rm.copy_(rm32)
                 rv.copy_(rv32)
         else:
             mean = invstd = None
             scale, shift = ops.bn_eval_coeffs(g32, b32, _f32(rm), _f32(rv), eps)
-        if res is not None:
-            res = _as_nhwc(res, T)
         out = ops.bn_act_fwd(y, scale, shift, act, res)
+        saved = (scale, shift, mean, invstd, g32)
         ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype, stem)
-        ctx.save_for_backward(x, weight, y, scale, shift, mean, invstd, g32)
+        ctx.save_for_backward(x, weight, y, *saved)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         k, stride, depthwise, act, training, xshape, has_res, gdtype, stem = ctx.cfg
-        x, weight, y, scale, shift, mean, invstd, g32 = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors[:3]
         T = y.dtype
         dout = _as_nhwc(dout, T)
+        scale, shift, mean, invstd, g32 = ctx.saved_tensors[3:]
         if training:
             dy, dgamma, dbeta = ops.bn_act_bwd(dout, y, scale, shift, mean, invstd, g32, act)
         else:

@@ -125,13 +125,64 @@ def conv_out_hw(h, w, k, stride):
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
-def conv_fwd(x, wp, bias, cout, k, stride):
+def conv_fwd(x, wp, bias, cout, k, stride, stats_acc=None):
+    """y = conv(x); with stats_acc (fp32 [8][2][cout], zeroed) also accumulates sum(y), sum(y^2) per channel."""
     n, cin, h, w, ldx = geom(x)
     oh, ow = conv_out_hw(h, w, k, stride)
     y = new_nhwc(n, cout, oh, ow, x.dtype, x.device)
-    lib.call("yolo_conv2d_fwd", _p(x), ldx, _p(wp), _p(bias), _p(y), cout, n, h, w, cin, oh, ow, cout, k, stride,
-             dt(x), ALGO, _stream(x))
+    lib.call("yolo_conv2d_fwd", _p(x), ldx, _p(wp), _p(bias), _p(y), cout, _p(stats_acc), n, h, w, cin, oh, ow, cout, k,
+             stride, dt(x), ALGO, _stream(x))
     return y
+
+
+BN_REPL = 8
+
+
+def bn_acc_new(c, device):
+    """Zeroed statistics accumulator for one BN layer: fp32 [8][2][c]."""
+    return zero_(torch.empty(BN_REPL * 2 * c, dtype=torch.float32, device=device))
+
+
+def bn_stats_acc(y, acc):
+    n, c, h, w, ld = geom(y)
+    lib.call("yolo_bn_stats_acc", _p(y), ld, n * h * w, c, dt(y), _p(acc), _stream(y))
+
+
+def bn_finalize_acc(acc, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """Accumulated (sum, sum of squares) -> (mean, invstd, scale, shift); updates the running buffers."""
+    c = gamma.numel()
+    coef = _f32(4 * c, gamma.device)
+    mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
+    lib.call("yolo_bn_finalize_acc", _p(acc), count, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+             float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), _stream(gamma))
+    return mean, invstd, scale, shift
+
+
+def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, eps, act, res=None):
+    """act(BN(y)) (+res) with batch statistics read from acc; updates running stats; -> (out, mean, invstd)."""
+    n, c, h, w, ld = geom(y)
+    out = new_nhwc(n, c, h, w, y.dtype, y.device)
+    mean, invstd = _f32(c, y.device), _f32(c, y.device)
+    ldr = geom(res)[4] if res is not None else 0
+    lib.call("yolo_bn_act_fwd_train", _p(y), ld, _p(acc), n * h * w, _p(gamma), _p(beta), _p(running_mean),
+             _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(res), ldr, _p(out), c, n * h * w, c,
+             int(act), dt(y), _stream(y))
+    return out, mean, invstd
+
+
+def bn_act_bwd_train(dout, y, gamma, beta, mean, invstd, act, acc):
+    """Backward of act(BN_batch(y)): acc (zeroed) collects sum(dz), sum(dz*yhat); -> (dy, dgamma, dbeta)."""
+    n, c, h, w, ldy = geom(y)
+    ldd = geom(dout)[4]
+    npix = n * h * w
+    st = _stream(y)
+    lib.call("yolo_bn_bwd_reduce_acc", _p(dout), ldd, _p(y), ldy, _p(gamma), _p(beta), _p(mean), _p(invstd), npix, c,
+             int(act), dt(y), _p(acc), st)
+    dgamma, dbeta = _f32(c, y.device), _f32(c, y.device)
+    dy = new_nhwc(n, c, h, w, y.dtype, y.device)
+    lib.call("yolo_bn_act_bwd_apply_train", _p(dout), ldd, _p(y), ldy, _p(gamma), _p(beta), _p(mean), _p(invstd), _p(acc),
+             npix, _p(dgamma), _p(dbeta), _p(dy), c, npix, c, int(act), dt(y), st)
+    return dy, dgamma, dbeta
 
 
 def conv_dgrad(dy, wb, cin, h, w, k, stride):

@@ -5,6 +5,7 @@ from typing import List
 import torch
 from torch import nn
 
+from src.hipops import functions as F_
 from src.hipops import ops
 from src.model.backbone import Backbone
 from src.model.head import Head
@@ -29,10 +30,16 @@ class Model(nn.Module):
                 m._count_batches = False
 
     def forward(self, x):
-        if self.training:
-            counters = [m.norm.num_batches_tracked for m in self.modules() if type(m) is Conv and hasattr(m, "norm")]
-            torch._foreach_add_(counters, 1)
-        return self.head(list(self.fpn(self.net(x))))
+        if not self.training:
+            return self.head(list(self.fpn(self.net(x))))
+        convs = [m for m in self.modules() if type(m) is Conv and hasattr(m, "norm")]
+        torch._foreach_add_([m.norm.num_batches_tracked for m in convs], 1)
+        # one zeroed pool for every layer's BatchNorm accumulators of this pass (a single memset)
+        F_.BnArena.current = F_.BnArena(x.device, F_.BnArena.elems_for([m.conv.out_channels for m in convs]))
+        try:
+            return self.head(list(self.fpn(self.net(x))))
+        finally:
+            F_.BnArena.current = None
 
     def fuse(self):
         """Fold every Conv's BatchNorm into its conv (inference only), reference :52-58."""

@@ -50,7 +50,7 @@ int yolo_conv_kpad(int O, int I, int k, int stride, int mode, int cls);
 long yolo_conv_dgrad_wbuf_elems(int O, int I, int k, int stride);
 int yolo_conv_pack_weights(const void* w_oihw, int w_dtype, int O, int I, int k, int stride, int mode, void* out, int out_dtype, hipStream_t st);
 int yolo_conv_unpack_wgrad(const float* dwp, int O, int I, int k, void* dw_oihw, int dw_dtype, hipStream_t st);
-int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
+int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dwp, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 /* stem (3 -> C, 3x3 stride 2: backbone.py:38): NCHW image unfolded to K = 27(+5) columns, then the 1x1 MFMA path */
@@ -73,6 +73,13 @@ int yolo_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shi
 int yolo_bn_act_bwd_reduce(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* partial, int nblk, hipStream_t st);
 int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st);
 int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, const float* coef, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
+/* accumulator form used by the training path: sums live in a caller-zeroed fp32 acc[8][2][C]; no finalize launches */
+int yolo_bn_acc_elems(int C);
+int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int dtype, float* acc, hipStream_t st);
+int yolo_bn_finalize_acc(const float* acc, long count, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
+int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype, hipStream_t st);
+int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta, const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* acc, hipStream_t st);
+int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta, const float* mean, const float* invstd, const float* acc, long count, float* dgamma, float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
 
 /* ---- SPPF max pool (model_blocks.py:150-156) and nearest x2 upsample (neck.py:31,41-42) */
 int yolo_maxpool5_fwd(const void* x, int ldx, void* out, int ldo, uint8_t* idx, int N, int H, int W, int C, int dtype, hipStream_t st);

@@ -56,9 +56,49 @@ def pack_weights(w, k, stride, mode, dtype):
     return w.detach().to(dtype)           # stand-in handle: the OIHW weights rounded to the compute dtype
 
 
-def conv_fwd(x, wp, bias, cout, k, stride):
-    y = F.conv2d(x.float(), wp.float(), bias, stride, k // 2)
-    return _nhwc(y.to(x.dtype))
+def conv_fwd(x, wp, bias, cout, k, stride, stats_acc=None):
+    y = _nhwc(F.conv2d(x.float(), wp.float(), bias, stride, k // 2).to(x.dtype))
+    if stats_acc is not None:
+        bn_stats_acc(y, stats_acc)
+    return y
+
+
+def bn_stats_acc(y, acc):
+    c = y.shape[1]
+    a = acc.view(real.BN_REPL, 2, c)
+    yf = y.float()
+    a[0, 0] += yf.sum((0, 2, 3))
+    a[0, 1] += (yf * yf).sum((0, 2, 3))
+
+
+def bn_finalize_acc(acc, count, gamma, beta, running_mean, running_var, momentum, eps):
+    c = gamma.numel()
+    s = acc.view(real.BN_REPL, 2, c).sum(0)
+    mean = s[0] / count
+    var = (s[1] / count - mean * mean).clamp_min(0)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    running_mean.mul_(1 - momentum).add_(momentum * mean)
+    running_var.mul_(1 - momentum).add_(momentum * var * (count / max(count - 1, 1)))
+    scale = gamma * invstd
+    return mean, invstd, scale, beta - mean * scale
+
+
+def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, eps, act, res=None):
+    c = y.shape[1]
+    cnt = y.numel() // c
+    s = acc.view(real.BN_REPL, 2, c).sum(0)
+    mean = s[0] / cnt
+    var = (s[1] / cnt - mean * mean).clamp_min(0)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    running_mean.mul_(1 - momentum).add_(momentum * mean)
+    running_var.mul_(1 - momentum).add_(momentum * var * (cnt / max(cnt - 1, 1)))
+    scale = gamma * invstd
+    return bn_act_fwd(y, scale, beta - mean * scale, act, res), mean, invstd
+
+
+def bn_act_bwd_train(dout, y, gamma, beta, mean, invstd, act, acc):
+    scale = gamma * invstd
+    return bn_act_bwd(dout, y, scale, beta - mean * scale, mean, invstd, gamma, act)
 
 
 def conv_dgrad(dy, wb, cin, h, w, k, stride):
@@ -249,7 +289,7 @@ def nms(y, nc, conf_thres, iou_thres, classes, agnostic, multi_label, max_det):
 
 
 LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "zero_", "fill_", "pack_weights", "conv_fwd",
-          "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad",
+          "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad", "bn_stats_acc", "bn_finalize_acc", "bn_act_fwd_train", "bn_act_bwd_train",
           "conv_dgrad", "conv_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "bn_train_stats", "bn_eval_coeffs",
           "bn_act_fwd", "bn_act_bwd", "bn_act_bwd_eval", "channel_sum", "maxpool5_fwd", "maxpool5_bwd",
           "upsample2x_fwd", "upsample2x_bwd", "attn_fwd", "attn_bwd", "loss_fwd_bwd", "scale_inplace", "head_decode",

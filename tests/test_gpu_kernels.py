@@ -188,6 +188,45 @@ def test_bn_act_train_fwd_bwd(dtype, c, act, pad):
     check(sc, sc_r, torch.float32, "eval scale"), check(sh, sh_r, torch.float32, "eval shift")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,h,w,k,s,act", [(16, 32, 20, 20, 3, 1, 1), (32, 128, 17, 13, 1, 1, 0), (64, 24, 16, 16, 3, 2, 1)])
+def test_bn_accumulator_path_with_conv_epilogue_stats(dtype, cin, cout, h, w, k, s, act):
+    """conv writes y AND its channel sums; act kernel derives mean/invstd; backward reduce + apply from acc."""
+    o = ops()
+    n = 4
+    x = nhwc(rnd(n, cin, h, w, seed=60).to(dtype))
+    wt = rnd(cout, cin, k, k, seed=61, scale=(cin * k * k) ** -0.5)
+    gamma, beta = 1 + 0.1 * rnd(cout, seed=62), 0.1 * rnd(cout, seed=63)
+    rm, rv = 0.1 * rnd(cout, seed=64), 1 + 0.1 * rnd(cout, seed=65).abs()
+    rm_g, rv_g = rm.clone().to(DEV), rv.clone().to(DEV)
+    acc_f, acc_b = o.bn_acc_new(cout, DEV), o.bn_acc_new(cout, DEV)
+    ref_f, ref_b = torch.zeros(8 * 2 * cout), torch.zeros(8 * 2 * cout)
+    y = o.conv_fwd(dev(x), o.pack_weights(wt.to(DEV), k, s, 0, dtype), None, cout, k, s, acc_f)
+    y_ref = emu.conv_fwd(x, emu.pack_weights(wt, k, s, 0, dtype), None, cout, k, s, ref_f)
+    check(y, y_ref, dtype, "conv y")
+    # statistics of the STORED values: compare with sums of the GPU's own y (isolates the epilogue reduction)
+    yf = y.float().cpu()
+    sums = acc_f.view(8, 2, cout).sum(0).cpu()
+    check(sums[0], yf.sum((0, 2, 3)), torch.float32, "epilogue sum", mult=20.0, scale=float(yf.abs().sum((0, 2, 3)).max()))
+    check(sums[1], (yf * yf).sum((0, 2, 3)), torch.float32, "epilogue sumsq", mult=20.0)
+    fin = o.bn_finalize_acc(acc_f, n * y.shape[2] * y.shape[3], gamma.to(DEV), beta.to(DEV), rm.clone().to(DEV), rv.clone().to(DEV), 0.03, 1e-3)
+    fin_r = emu.bn_finalize_acc(ref_f, n * y.shape[2] * y.shape[3], gamma, beta, rm.clone(), rv.clone(), 0.03, 1e-3)
+    for a_, b_, nm in zip(fin, fin_r, ("mean", "invstd", "scale", "shift")):
+        check(a_, b_, torch.float32, "finalize_acc " + nm, mult=100.0 if dtype != torch.float32 else 4.0, scale=max(1.0, float(b_.abs().max())))
+    res = nhwc(rnd(*y_ref.shape, seed=66).to(dtype))
+    out, mean, invstd = o.bn_act_fwd_train(y, acc_f, gamma.to(DEV), beta.to(DEV), rm_g, rv_g, 0.03, 1e-3, act, dev(res))
+    out_r, mean_r, invstd_r = emu.bn_act_fwd_train(y_ref, ref_f, gamma, beta, rm, rv, 0.03, 1e-3, act, res)
+    check(mean, mean_r, torch.float32, "mean", mult=50.0 if dtype != torch.float32 else 4.0, scale=float(y_ref.float().abs().max()))
+    check(invstd, invstd_r, torch.float32, "invstd", mult=100.0 if dtype != torch.float32 else 4.0)
+    check(out, out_r, dtype, "bn_act_fwd_train", mult=2.0)
+    check(rm_g, rm, torch.float32, "running_mean", mult=50.0), check(rv_g, rv, torch.float32, "running_var", mult=100.0)
+    dout = nhwc(rnd(*y_ref.shape, seed=67).to(dtype))
+    dy, dg, db = o.bn_act_bwd_train(dev(dout), y, gamma.to(DEV), beta.to(DEV), mean, invstd, act, acc_b)
+    dy_r, dg_r, db_r = emu.bn_act_bwd_train(dout, y.cpu(), gamma, beta, mean.cpu(), invstd.cpu(), act, ref_b)
+    check(dy, dy_r, dtype, "bn bwd dy", mult=2.0)
+    check(dg, dg_r, torch.float32, "dgamma", mult=20.0), check(db, db_r, torch.float32, "dbeta", mult=20.0)
+
+
 # ------------------------------------------------------------------------------------------ pool / upsample
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool5_and_upsample(dtype):
