@@ -1,0 +1,48 @@
+"""-m gpu: the reference's call sequence end to end on one GPU -- init_distributed_mode (RCCL, world 1),
+prepare_{ddp,fsdp2}_model, get_optimizer, get_data_loaders (synthetic), train() for one short epoch incl.
+validation decode/metrics and the rank-0 checkpoint -- i.e. what scripts/distributed_training.py does."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+NANO = dict(csp=[False, True], depth=[1] * 6, width=[3, 16, 32, 64, 128, 256])
+
+
+@pytest.fixture(scope="module")
+def pg():
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    from src.training.distributed_setup import cleanup_distribute_mode, init_distributed_mode
+    yield init_distributed_mode("cuda")
+    cleanup_distribute_mode()
+
+
+@pytest.mark.parametrize("mode,precision", [("ddp", "bfloat16"), ("ddp", "float32"), ("fsdp2", "bfloat16")])
+def test_train_one_epoch_like_the_script(pg, mode, precision, tmp_path):
+    from src.data.data_loader import get_data_loaders
+    from src.model.losses import YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.train_model import train
+    from src.training.utils_train import get_optimizer, prepare_ddp_model, prepare_fsdp2_model
+    rank, world, gpu = pg
+    torch.manual_seed(0)
+    model = Model(**NANO, num_classes=80)
+    wrap = prepare_ddp_model if mode == "ddp" else prepare_fsdp2_model
+    model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False},
+                 world_size=world, device="cuda")
+    tr, va = get_data_loaders("/nonexistent/train", "/nonexistent/val", "", "", batch_size=4, is_test=True, device="cuda",
+                              num_classes=80, res=160)
+    opt, sched = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
+    before = [p.detach().float().clone() for p in model.parameters()][:3]
+    train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched,
+          criterion=YoloDFLQFLoss(num_classes=80), initial_epoch=0, num_epochs=1, device=gpu, num_classes=80, rank=rank,
+          checkpoint_dir=str(tmp_path), distributed_mode=mode, precision=precision, conf_threshold=0.01)
+    after = [p.detach().float() for p in model.parameters()][:3]
+    assert any(not torch.equal(a, b) for a, b in zip(before, after)), "parameters did not move"
+    assert all(torch.isfinite(a).all() for a in after)
+    ck = torch.load(os.path.join(str(tmp_path), "model_epoch_1.pth"), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and "model_state" in ck and "optimizer_state" in ck
+    keys = set(ck["model_state"].keys())
+    assert any(k.endswith("net.p1.0.conv.weight") for k in keys) and any(k.endswith("head.dfl.conv.weight") for k in keys)
