@@ -107,8 +107,61 @@ def fill_(t, value):
 
 
 # ------------------------------------------------------------------------------------------------ conv
+class WeightPackPlan:
+    """Every dense conv weight of a model packed (forward + dgrad forms) by ONE launch per step.
+    `run()` re-packs from the current parameter values; `lookup()` serves pack_weights() while the
+    parameter has not been written since (tensor version check), so a stale plan can never be used."""
+
+    def __init__(self, convs, dtype):
+        """convs: list of (weight, k, stride) with plain (unsharded) OIHW parameters on one device."""
+        dev = convs[0][0].device
+        jb = lib.query("yolo_pack_job_bytes")
+        sizes, njobs = [], 0
+        for w, k, s in convs:
+            o, i = w.shape[0], w.shape[1]
+            sizes.append((o * lib.query("yolo_conv_kpad", o, i, k, s, 0, 0), lib.query("yolo_conv_dgrad_wbuf_elems", o, i, k, s)))
+            njobs += 1 + lib.query("yolo_pack_job_count", s, 1)
+        self.dtype, self.njobs = dtype, njobs
+        self.total = sum(a + b for a, b in sizes)
+        self.flat = torch.empty(self.total, dtype=dtype, device=dev)
+        host = torch.zeros(njobs * jb, dtype=torch.uint8)
+        self.entries, start, ji = {}, 0, 0
+        esz = self.flat.element_size()
+        for (w, k, s), (nf, nb) in zip(convs, sizes):
+            o, i = w.shape[0], w.shape[1]
+            for mode, n in ((0, nf), (1, nb)):
+                view = self.flat[start:start + n]
+                got = lib.query("yolo_pack_job_fill", host.data_ptr() + ji * jb, w.data_ptr(), dt(w), view.data_ptr(), esz,
+                                o, i, k, s, mode, start)
+                assert got == n, (got, n)
+                self.entries[(w.data_ptr(), mode)] = [view, w, -1]
+                ji += 1 if mode == 0 else lib.query("yolo_pack_job_count", s, 1)
+                start += n
+        self.nchunks = lib.query("yolo_pack_jobs_finalize", host.data_ptr(), njobs)
+        self.jobs = host.to(dev)
+        self.key = tuple(w.data_ptr() for w, _, _ in convs)
+
+    def run(self):
+        lib.call("yolo_pack_batched", _p(self.jobs), self.njobs, self.nchunks, dt(self.dtype), _stream(self.flat))
+        for e in self.entries.values():
+            e[2] = e[1]._version
+
+    def lookup(self, w, mode, dtype):
+        e = self.entries.get((w.data_ptr(), mode))
+        if e is None or dtype != self.dtype or e[2] != w._version or w.shape != e[1].shape:
+            return None
+        return e[0]
+
+
+ACTIVE_PACK_PLAN = None
+
+
 def pack_weights(w, k, stride, mode, dtype):
     """OIHW parameter -> K-major packed matrix (mode 0 forward, 1 dgrad buffer) in the compute dtype."""
+    if ACTIVE_PACK_PLAN is not None:
+        hit = ACTIVE_PACK_PLAN.lookup(w, mode, dtype)
+        if hit is not None:
+            return hit
     o, i = w.shape[0], w.shape[1]
     w = w if w.is_contiguous() else w.contiguous()
     if mode == 0:

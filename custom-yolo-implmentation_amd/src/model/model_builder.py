@@ -34,12 +34,31 @@ class Model(nn.Module):
             return self.head(list(self.fpn(self.net(x))))
         convs = [m for m in self.modules() if type(m) is Conv and hasattr(m, "norm")]
         torch._foreach_add_([m.norm.num_batches_tracked for m in convs], 1)
+        self._prepack(x, convs)
         # one zeroed pool for every layer's BatchNorm accumulators of this pass (a single memset)
         F_.BnArena.current = F_.BnArena(x.device, F_.BnArena.elems_for([m.conv.out_channels for m in convs]))
         try:
             return self.head(list(self.fpn(self.net(x))))
         finally:
             F_.BnArena.current = None
+
+    def _prepack(self, x, convs):
+        """Pack every dense conv weight (forward + dgrad forms) with one launch instead of two per layer.
+        Only for plain local parameters; sharded/wrapped parameters (FSDP) fall back to per-layer packing."""
+        ops.ACTIVE_PACK_PLAN = None
+        if not getattr(self, "prepack", False):      # opt-in (TrainStepRunner): parameters must be plain, stable
+            return                                   # local tensors -- never under FSDP, whose buffers come and go
+        dense = [(m.conv.weight, m._k, m._s) for m in convs if not m._dw and m.conv.weight.shape[1] != 3]
+        dense += [(b[-1].weight, 1, 1) for br in (self.head.box, self.head.cls) for b in br]
+        if any(type(w.data) is not torch.Tensor or not w.is_cuda for w, _, _ in dense):
+            return
+        T = F_.compute_dtype(x, dense[0][0])
+        key = (T, tuple(w.data_ptr() for w, _, _ in dense))
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or (plan.dtype, plan.key) != key:
+            plan = self._pack_plan = ops.WeightPackPlan(dense, T)
+        plan.run()
+        ops.ACTIVE_PACK_PLAN = plan
 
     def fuse(self):
         """Fold every Conv's BatchNorm into its conv (inference only), reference :52-58."""

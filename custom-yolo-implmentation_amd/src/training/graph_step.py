@@ -20,6 +20,8 @@ class TrainStepRunner:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.comm_dtype = grad_comm_dtype
         self.params = [p for p in model.parameters() if p.requires_grad]
+        if hasattr(model, "_prepack"):          # plain local parameters here: pack all conv weights in one launch
+            model.prepack = True
         self.graph = None
         self.opt_in_graph = False
         self.static = None

@@ -50,6 +50,11 @@ int yolo_conv_kpad(int O, int I, int k, int stride, int mode, int cls);
 long yolo_conv_dgrad_wbuf_elems(int O, int I, int k, int stride);
 int yolo_conv_pack_weights(const void* w_oihw, int w_dtype, int O, int I, int k, int stride, int mode, void* out, int out_dtype, hipStream_t st);
 int yolo_conv_unpack_wgrad(const float* dwp, int O, int I, int k, void* dw_oihw, int dw_dtype, hipStream_t st);
+int yolo_pack_job_bytes();
+int yolo_pack_job_count(int stride, int mode);
+long yolo_pack_job_fill(void* jobs_host, const void* w, int w_dtype, void* out, int out_elem_bytes, int O, int I, int k, int stride, int mode, long start);
+long yolo_pack_jobs_finalize(void* jobs_host, int njobs);
+int yolo_pack_batched(const void* jobs_dev, int njobs, long nchunks, int out_dtype, hipStream_t st);
 int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dwp, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);

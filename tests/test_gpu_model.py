@@ -116,6 +116,35 @@ def test_bf16_autocast_step_vs_fp32_oracle(res, n):
     assert _rel(preds, p_ref) < 2 * _rel(p16, p_ref) + 1e-2
 
 
+def test_batched_weight_packing_equals_per_layer_packing():
+    """Model.prepack (one launch for all conv weights) must reproduce the per-layer packed matrices bit for bit,
+    and a parameter update must invalidate the served copies."""
+    from src.hipops import ops
+    model = _model(seed=5).train()
+    model.prepack = True
+    img = torch.randn(2, 3, 96, 96, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        model(img)
+    plan = ops.ACTIVE_PACK_PLAN
+    assert plan is not None and plan.njobs > 100
+    n = 0
+    for (ptr, mode), (view, w, ver) in plan.entries.items():
+        o, i, k = w.shape[0], w.shape[1], w.shape[2]
+        s = 2 if any(m.conv.weight is w and m._s == 2 for m in model.modules() if hasattr(m, "_s")) else 1
+        ops.ACTIVE_PACK_PLAN = None
+        ref = ops.pack_weights(w, k, s, mode, torch.bfloat16)
+        ops.ACTIVE_PACK_PLAN = plan
+        assert torch.equal(view, ref), (tuple(w.shape), mode)
+        assert ops.pack_weights(w, k, s, mode, torch.bfloat16).data_ptr() == view.data_ptr()
+        n += 1
+    w0 = model.net.p2[0].conv.weight
+    with torch.no_grad():
+        w0.add_(1.0)                                   # version bump -> the plan must refuse to serve it
+    assert plan.lookup(w0, 0, torch.bfloat16) is None
+    ops.ACTIVE_PACK_PLAN = None
+    assert n > 100
+
+
 def test_small_preset_640_bf16_step_runs_and_is_finite():
     """BASELINE config 2's model at a reduced batch: shapes, finiteness, every parameter gets a gradient."""
     from src.model.losses import YoloDFLQFLoss
