@@ -45,7 +45,7 @@ class KernelTimer:
     """Brackets selected leaf ops with events on torch's current stream (the stream the kernels launch on)."""
 
     def __init__(self, ops):
-        self.ops, self.rec, self.saved = ops, [], {}
+        self.ops, self.rec, self.saved, self.detail = ops, [], {}, []
 
     def _wrap(self, name, group, flops_fn, bytes_fn):
         fn = getattr(self.ops, name)
@@ -57,6 +57,9 @@ class KernelTimer:
             out = fn(*a, **k)
             e1.record()
             self.rec.append((group, e0, e1, flops_fn(out, *a) if flops_fn else 0.0, bytes_fn(out, *a) if bytes_fn else 0.0))
+            if os.environ.get("BENCH_VERBOSE"):
+                shapes = [tuple(t.shape) for t in a if isinstance(t, torch.Tensor) and t.dim() == 4]
+                self.detail.append((name, shapes, [x for x in a if isinstance(x, int)], len(self.rec) - 1))
             return out
         setattr(self.ops, name, timed)
 
@@ -98,6 +101,14 @@ class KernelTimer:
 
     def summary(self):
         torch.cuda.synchronize()
+        if self.detail:          # BENCH_VERBOSE=1: the 40 longest leaf calls with shapes, TFLOP/s and GB/s
+            rows = []
+            for name, shapes, ints, i in self.detail:
+                _, e0, e1, fl, by = self.rec[i]
+                ms = e0.elapsed_time(e1)
+                rows.append((ms, name, shapes, ints, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0))
+            for ms, name, shapes, ints, tf, gbs in sorted(rows, key=lambda r: -r[0])[:40]:
+                print(f"[detail] {1e3 * ms:8.1f} us {name:14s} {tf:7.1f} TF/s {gbs:7.0f} GB/s {shapes} {ints}", file=sys.stderr)
         groups = {}
         for grp, e0, e1, fl, by in self.rec:
             g = groups.setdefault(grp, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))

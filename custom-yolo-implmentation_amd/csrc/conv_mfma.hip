@@ -361,8 +361,14 @@ void launch_tile(const GeomDev& d, const void* src, const void* wm, const float*
 template <typename T>
 void launch_conv_t(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                    hipStream_t st) {
-    if (d.Cd > 64) launch_tile<T, 2, 2, 4, 4>(d, src, wm, bias, dst, accumulate, st);        // 128 x 128
-    else if (d.Cd > 32) launch_tile<T, 2, 2, 4, 2>(d, src, wm, bias, dst, accumulate, st);   // 128 x 64
+    // widest channel tile that still yields >= 2 workgroups per CU; small maps with many channels (20x20, K in
+    // the thousands) otherwise run ~100 workgroups through a 144-step K loop on a 256-CU chip
+    const long tm = ((long)d.N * d.Hg * d.Wg + BM - 1) / BM;
+    auto blocks = [&](int bn) { return tm * ((d.Cd + bn - 1) / bn); };
+    int bn = d.Cd > 64 ? 128 : (d.Cd > 32 ? 64 : 32);
+    while (bn > 32 && blocks(bn) < 512) bn >>= 1;
+    if (bn == 128) launch_tile<T, 2, 2, 4, 4>(d, src, wm, bias, dst, accumulate, st);        // 128 x 128
+    else if (bn == 64) launch_tile<T, 2, 2, 4, 2>(d, src, wm, bias, dst, accumulate, st);    // 128 x 64
     else launch_tile<T, 4, 1, 2, 2>(d, src, wm, bias, dst, accumulate, st);                  // 128 x 32
 }
 

@@ -252,10 +252,17 @@ __global__ __launch_bounds__(256) void k_matched(LossDims d, const T* __restrict
 
 __global__ void k_finish(LossDims d, const double* __restrict__ partial, int nblk, const double* __restrict__ img_dfl,
                          const double* __restrict__ img_cls_fix, float* __restrict__ out) {
-    if (threadIdx.x || blockIdx.x) return;
+    // one wave: lanes sum strided slices (a single thread walking 2048 partials took 113 us), then a
+    // fixed-order butterfly -- still deterministic
     double cls = 0.0, dfl = 0.0;
-    for (int b = 0; b < nblk; ++b) cls += partial[b];
-    for (int n = 0; n < d.N; ++n) { cls += img_cls_fix[n]; dfl += img_dfl[n]; }
+    for (int b = threadIdx.x; b < nblk; b += 64) cls += partial[b];
+    for (int n = threadIdx.x; n < d.N; n += 64) { cls += img_cls_fix[n]; dfl += img_dfl[n]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cls += __shfl_xor(cls, o, 64);
+        dfl += __shfl_xor(dfl, o, 64);
+    }
+    if (threadIdx.x) return;
     double mean_cls = cls / (double)d.A / (double)d.N, mean_dfl = dfl / (double)d.N;
     out[0] = (float)(d.lambda_dfl * mean_dfl + d.lambda_cls * mean_cls);
     out[1] = (float)mean_dfl;

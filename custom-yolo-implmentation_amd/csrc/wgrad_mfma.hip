@@ -161,8 +161,11 @@ void launch(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStrea
     // each workgroup ends with KS*KS*(32*TCO)*(32*TCI) fp32 atomics (147 KB for a 3x3 64x64 tile): keep the
     // workgroup count at ~2 per CU for 3x3 so that flush stays far below the pixel traffic
     long want = (KS == 3 ? 512 : 2048) / ((long)cot * cit);
+    // ... and give every workgroup at least ~16 patches (3x3) before it flushes: on small maps one-patch
+    // workgroups spent 100+ us hammering the same 147 KB with atomics (64->64 3x3 @20x20: 117 us, 8 TFLOP/s)
+    const long min_per = KS == 3 ? 16 : 4;
+    if (want > a.npatch / min_per) want = a.npatch / min_per;
     if (want < 1) want = 1;
-    if (want > a.npatch) want = a.npatch;
     b.per_slab = (a.npatch + want - 1) / want;
     const int nslab = (int)((a.npatch + b.per_slab - 1) / b.per_slab);
     hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI>), dim3(cot, cit, nslab), dim3(256), 0, st, b, (const T*)x, (const T*)dy, dwp);
