@@ -52,7 +52,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <typename T, int WGM, int WGN, int WM, int WN, bool ACC>
+template <typename T, int WGM, int WGN, int WM, int WN, bool ACC, bool SMALLC>
 __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
                                                    const float* __restrict__ bias, T* __restrict__ dst, int ntile_n) {
     static_assert(WGM * WGN == 4 && WGM * WM * 16 == BM, "tile shape");
@@ -73,21 +73,21 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
     // ---- loader state: two activation rows (r, r+64) and one weight row per thread, fixed k-segment
     const int kseg = tid & 3;
     const int lrow = tid >> 2;                      // 0..63
-    long pbase[2];                                  // ((n*Hs)*Ws) pixel base of the image
-    int hs0[2], ws0[2];
-    bool rvalid[2];
+    // Per row: 32-bit element offset of its (n, hs0, ws0) source pixel and the two coordinates for the bounds
+    // test (rows past the end get coordinates that fail every test).  The host guarantees < 2^31 elements.
+    int rowoff[2], hs0[2], ws0[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         long q = m0 + lrow + i * 64;
-        rvalid[i] = q < total_pix;
-        long qq = rvalid[i] ? q : 0;
+        const bool rv = q < total_pix;
+        long qq = rv ? q : 0;
         int b = (int)(qq % g.Wg);
         long t2 = qq / g.Wg;
         int a = (int)(t2 % g.Hg);
-        long n = t2 / g.Hg;
-        pbase[i] = n * g.Hs * (long)g.Ws;
-        hs0[i] = a * g.sstride;
+        int n = (int)(t2 / g.Hg);
+        hs0[i] = rv ? a * g.sstride : -(1 << 20);
         ws0[i] = b * g.sstride;
+        rowoff[i] = ((n * g.Hs + a * g.sstride) * g.Ws + b * g.sstride) * g.lds;
     }
     constexpr int WR = (BN + 63) / 64;              // weight rows per thread (lrow, lrow+64)
     bool wvalid[WR];
@@ -102,28 +102,28 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
     int tap = 0, ch = kseg * 8;                     // k = tap*Cs + ch for this thread's segment
     while (ch >= g.Cs) { ch -= g.Cs; ++tap; }
 
+    // The K loop is issue-bound by this gather, so it is kept lean: 32-bit offsets, unsigned range tests,
+    // loads from a clamped (always valid) address whose result is masked -- no divergent branches -- and the
+    // weight rows simply advance by BK (rows of invalid channels point at row 0 and are masked the same way).
     uint4 ra[2], rb[WR];
     auto gload = [&](int kt) {
-        int dh = 0, dw = 0;
-        bool tv = tap < g.ntaps;
-        if (tv) {
-            dh = (int)((g.dh_pack >> (2 * tap)) & 3u) - 1;
-            dw = (int)((g.dw_pack >> (2 * tap)) & 3u) - 1;
-        }
+        const bool tv = tap < g.ntaps;
+        const int dh = (int)((g.dh_pack >> (2 * tap)) & 3u) - 1, dw = (int)((g.dw_pack >> (2 * tap)) & 3u) - 1;
+        const int tapoff = (dh * g.Ws + dw) * g.lds + ch;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int hs = hs0[i] + dh, ws = ws0[i] + dw;
-            bool ok = tv && rvalid[i] && hs >= 0 && hs < g.Hs && ws >= 0 && ws < g.Ws;
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (ok) ra[i] = *reinterpret_cast<const uint4*>(src + (pbase[i] + (long)hs * g.Ws + ws) * g.lds + ch);
+            const bool ok = tv && (unsigned)(hs0[i] + dh) < (unsigned)g.Hs && (unsigned)(ws0[i] + dw) < (unsigned)g.Ws;
+            const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? rowoff[i] + tapoff : 0));
+            ra[i] = ok ? v : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (wvalid[i]) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (long)kt * BK);
+            const uint4 v = *reinterpret_cast<const uint4*>(wrow[i] + kt * BK);
+            rb[i] = wvalid[i] ? v : make_uint4(0, 0, 0, 0);
         }
         ch += BK;
-        while (ch >= g.Cs) { ch -= g.Cs; ++tap; }
+        if (SMALLC) { while (ch >= g.Cs) { ch -= g.Cs; ++tap; } }
+        else if (ch >= g.Cs) { ch -= g.Cs; ++tap; }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -350,12 +350,13 @@ void launch_tile(const GeomDev& d, const void* src, const void* wm, const float*
     long pix = (long)d.N * d.Hg * d.Wg;
     int tm = (int)((pix + BM - 1) / BM), tn = (d.Cd + BN - 1) / BN;
     dim3 grid(tm * tn);
-    if (accumulate)
-        hipLaunchKernelGGL((k_conv_mfma<T, WGM, WGN, WM, WN, true>), grid, dim3(256), 0, st, d, (const T*)src,
-                           (const T*)wm, bias, (T*)dst, tn);
-    else
-        hipLaunchKernelGGL((k_conv_mfma<T, WGM, WGN, WM, WN, false>), grid, dim3(256), 0, st, d, (const T*)src,
-                           (const T*)wm, bias, (T*)dst, tn);
+    const bool smallc = d.Cs < BK;       // a 32-wide K step can then cross more than one tap
+#define CONV_LAUNCH(ACC_, SM_)                                                                                        \
+    hipLaunchKernelGGL((k_conv_mfma<T, WGM, WGN, WM, WN, ACC_, SM_>), grid, dim3(256), 0, st, d, (const T*)src,       \
+                       (const T*)wm, bias, (T*)dst, tn)
+    if (accumulate) { if (smallc) CONV_LAUNCH(true, true); else CONV_LAUNCH(true, false); }
+    else { if (smallc) CONV_LAUNCH(false, true); else CONV_LAUNCH(false, false); }
+#undef CONV_LAUNCH
 }
 
 template <typename T>
@@ -379,6 +380,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst) {
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
     if (g.Cs % 8 || g.lds % 8 || g.Cd % 8 || g.ldd % 4) return 0;
+    if ((long)g.N * g.Hs * g.Ws * g.lds >= (1L << 31)) return 0;      // the gather uses 32-bit element offsets
     if (!al16(src) || !al16(wm) || (reinterpret_cast<uintptr_t>(dst) & 7)) return 0;
     for (int t = 0; t < g.ntaps; ++t)
         if (g.dh[t] < -1 || g.dh[t] > 1 || g.dw[t] < -1 || g.dw[t] > 1) return 0;
