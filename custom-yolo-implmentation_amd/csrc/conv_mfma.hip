@@ -38,7 +38,9 @@ template <> struct mfma_ops<f16_t> {
 
 constexpr int BM = 128;    // destination pixels per workgroup
 constexpr int BK = 32;     // K elements per step (one MFMA K)
-constexpr int LDSROW = 40; // elements per LDS row (32 + 8 pad) = 80 bytes
+constexpr int LDSROW = 32; // elements per LDS row: unpadded 64-byte rows whose four 16-byte chunks are XOR-swizzled
+                           // by (-(row >> 2)) & 3 -- conflict-free for ds_read_b128 fragment reads (16 rows x 1 chunk
+                           // per lane group) and for the ds_write_b128 staging (2 rows x 4 chunks per 8 lanes)
 
 struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic indexing of kernargs)
     int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, Hg, Wg, ostep, ooff_h, ooff_w, sstride, ntaps, KT, Kpad;
@@ -46,13 +48,34 @@ struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic i
     float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // bijective XCD-aware remap (guide T1): blocks that share an XCD get a contiguous range of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <typename T, int WGM, int WGN, int WM, int WN, bool ACC, bool SMALLC>
+// x + (x rotated by N lanes inside its row of 16): one VALU op (v_add_f32 with a DPP operand)
+template <int N> __device__ __forceinline__ float row_ror_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x = row_ror_add<8>(x);
+    x = row_ror_add<4>(x);
+    x = row_ror_add<2>(x);
+    return row_ror_add<1>(x);
+}
+
+// MODE 0: K walked tap-major (k = tap*Cs + ch), any Cs % 8 == 0; each lane tracks its own (tap, ch).
+// MODE 1: the same with Cs < 32 (a step can cross several taps).
+// MODE 2: Cs % 32 == 0.  K is walked channel-chunk-major with the taps innermost (a workgroup re-reads its
+//   input patch for all taps of one 32-channel chunk back to back, so the re-reads hit L2), the tap of a step is
+//   wave-uniform, and both operands come through buffer descriptors: the per-lane byte offset (voffset) is fixed
+//   for the whole loop, the step's tap / chunk / weight-column offset is one scalar (soffset), and a padding tap
+//   or a row past the end is a voffset beyond the descriptor's range, which the hardware reads as zero -- the
+//   gather costs 3 vector instructions per row and step.  All sizes are below 2^30 elements (host check).
+template <typename T, int WGM, int WGN, int WM, int WN, bool ACC, int MODE>
 __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
                                                    const float* __restrict__ bias, T* __restrict__ dst, int ntile_n) {
     static_assert(WGM * WGN == 4 && WGM * WM * 16 == BM, "tile shape");
@@ -66,78 +89,121 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
     const int nwg = gridDim.x;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int tile_m = tile / ntile_n, tile_n = tile - tile_m * ntile_n;
-    const long m0 = (long)tile_m * BM;
+    const int m0 = tile_m * BM;
     const int cd0 = tile_n * BN;
-    const long total_pix = (long)g.N * g.Hg * g.Wg;
+    const int total_pix = g.N * g.Hg * g.Wg;
 
-    // ---- loader state: two activation rows (r, r+64) and one weight row per thread, fixed k-segment
+    // ---- loader state: two activation rows (r, r+64) and up to two weight rows per thread, fixed k-segment
     const int kseg = tid & 3;
     const int lrow = tid >> 2;                      // 0..63
-    // Per row: 32-bit element offset of its (n, hs0, ws0) source pixel and the two coordinates for the bounds
-    // test (rows past the end get coordinates that fail every test).  The host guarantees < 2^31 elements.
-    int rowoff[2], hs0[2], ws0[2];
+    const int sk = (kseg ^ ((-(lrow >> 2)) & 3)) * 8;   // swizzled chunk this thread stores
+    int rowoff[2], hs0[2], ws0[2];                  // element offset of the row's (n, hs0, ws0) source pixel
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        long q = m0 + lrow + i * 64;
+        const int q = m0 + lrow + i * 64;
         const bool rv = q < total_pix;
-        long qq = rv ? q : 0;
-        int b = (int)(qq % g.Wg);
-        long t2 = qq / g.Wg;
-        int a = (int)(t2 % g.Hg);
-        int n = (int)(t2 / g.Hg);
-        hs0[i] = rv ? a * g.sstride : -(1 << 20);
-        ws0[i] = b * g.sstride;
-        rowoff[i] = ((n * g.Hs + a * g.sstride) * g.Ws + b * g.sstride) * g.lds;
+        const unsigned qq = rv ? q : 0;
+        const unsigned t2 = qq / (unsigned)g.Wg, b = qq - t2 * g.Wg;
+        const unsigned n = t2 / (unsigned)g.Hg, a = t2 - n * g.Hg;
+        hs0[i] = rv ? (int)a * g.sstride : -(1 << 20);     // rows past the end fail every bounds test
+        ws0[i] = (int)b * g.sstride;
+        rowoff[i] = (((int)n * g.Hs + (int)a * g.sstride) * g.Ws + (int)b * g.sstride) * g.lds;
     }
     constexpr int WR = (BN + 63) / 64;              // weight rows per thread (lrow, lrow+64)
     bool wvalid[WR];
-    const T* wrow[WR];
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-        int r = lrow + i * 64;
+        const int r = lrow + i * 64;
         wvalid[i] = (r < BN) && (cd0 + r < g.Cd);
-        wrow[i] = wm + (long)(cd0 + (wvalid[i] ? r : 0)) * g.Kpad + kseg * 8;
     }
 
-    int tap = 0, ch = kseg * 8;                     // k = tap*Cs + ch for this thread's segment
-    while (ch >= g.Cs) { ch -= g.Cs; ++tap; }
-
-    // The K loop is issue-bound by this gather, so it is kept lean: 32-bit offsets, unsigned range tests,
-    // loads from a clamped (always valid) address whose result is masked -- no divergent branches -- and the
-    // weight rows simply advance by BK (rows of invalid channels point at row 0 and are masked the same way).
     uint4 ra[2], rb[WR];
+
+    // MODE 2 state
+    unsigned vmask[2] = {0u, 0u};                   // bit t: tap t of this row is inside the source image
+    int voffa[2], voffb[WR];
+    int tap = 0, cbase = 0, wcol = 0;               // uniform
+    __amdgpu_buffer_rsrc_t rsa, rsb;
+    // MODE 0/1 state
+    int ltap = 0, ch = kseg * 8;
+    const T* wrow[WR];
+
+    if constexpr (MODE == 2) {
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int dh = (int)((g.dh_pack >> (2 * t)) & 3u) - 1, dw = (int)((g.dw_pack >> (2 * t)) & 3u) - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = (unsigned)(hs0[i] + dh) < (unsigned)g.Hs && (unsigned)(ws0[i] + dw) < (unsigned)g.Ws;
+                vmask[i] |= (ok ? 1u : 0u) << t;
+            }
+        }
+        // descriptor base = src - one row - one pixel, so the scalar tap offset (dh+1, dw+1) is never negative
+        const int shift = (g.Ws + 1) * g.lds;
+        rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src) - shift, 0, (g.N * g.Hs * g.Ws * g.lds + shift) * 2,
+                                                0x00020000);
+        rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wm), 0, g.Cd * g.Kpad * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) voffa[i] = (rowoff[i] + kseg * 8) * 2;
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            voffb[i] = wvalid[i] ? ((cd0 + lrow + i * 64) * g.Kpad + kseg * 8) * 2 : (int)0x80000000;
+    } else {
+#pragma unroll
+        for (int i = 0; i < WR; ++i) wrow[i] = wm + (long)(cd0 + (wvalid[i] ? lrow + i * 64 : 0)) * g.Kpad + kseg * 8;
+        while (ch >= g.Cs) { ch -= g.Cs; ++ltap; }
+    }
+
     auto gload = [&](int kt) {
-        const bool tv = tap < g.ntaps;
-        const int dh = (int)((g.dh_pack >> (2 * tap)) & 3u) - 1, dw = (int)((g.dw_pack >> (2 * tap)) & 3u) - 1;
-        const int tapoff = (dh * g.Ws + dw) * g.lds + ch;
+        if constexpr (MODE == 2) {
+            const int soff = ((int)((g.dh_pack >> (2 * tap)) & 3u) * g.Ws + (int)((g.dw_pack >> (2 * tap)) & 3u)) * g.lds + cbase;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool ok = tv && (unsigned)(hs0[i] + dh) < (unsigned)g.Hs && (unsigned)(ws0[i] + dw) < (unsigned)g.Ws;
-            const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? rowoff[i] + tapoff : 0));
-            ra[i] = ok ? v : make_uint4(0, 0, 0, 0);
-        }
+            for (int i = 0; i < 2; ++i) {
+                const int vo = ((vmask[i] >> tap) & 1u) ? voffa[i] : (int)0x80000000;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsa, vo, soff * 2, 0);
+                ra[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const uint4 v = *reinterpret_cast<const uint4*>(wrow[i] + kt * BK);
-            rb[i] = wvalid[i] ? v : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < WR; ++i) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsb, voffb[i], wcol * 2, 0);
+                rb[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+            ++tap;
+            wcol += g.Cs;
+            if (tap == g.ntaps) { tap = 0; cbase += BK; wcol += BK - g.ntaps * g.Cs; }
+        } else {
+            const bool tv = ltap < g.ntaps;
+            const int dh = (int)((g.dh_pack >> (2 * ltap)) & 3u) - 1, dw = (int)((g.dw_pack >> (2 * ltap)) & 3u) - 1;
+            const int tapoff = (dh * g.Ws + dw) * g.lds + ch;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = tv && (unsigned)(hs0[i] + dh) < (unsigned)g.Hs && (unsigned)(ws0[i] + dw) < (unsigned)g.Ws;
+                const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? rowoff[i] + tapoff : 0));
+                ra[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                const uint4 v = *reinterpret_cast<const uint4*>(wrow[i] + kt * BK);
+                rb[i] = wvalid[i] ? v : make_uint4(0, 0, 0, 0);
+            }
+            ch += BK;
+            if (MODE == 1) { while (ch >= g.Cs) { ch -= g.Cs; ++ltap; } }
+            else if (ch >= g.Cs) { ch -= g.Cs; ++ltap; }
         }
-        ch += BK;
-        if (SMALLC) { while (ch >= g.Cs) { ch -= g.Cs; ++tap; } }
-        else if (ch >= g.Cs) { ch -= g.Cs; ++tap; }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint4*>(&lds_a[buf][lrow + i * 64][kseg * 8]) = ra[i];
+            *reinterpret_cast<uint4*>(&lds_a[buf][lrow + i * 64][sk]) = ra[i];
 #pragma unroll
         for (int i = 0; i < WR; ++i)
-            if (lrow + i * 64 < BN) *reinterpret_cast<uint4*>(&lds_b[buf][lrow + i * 64][kseg * 8]) = rb[i];
+            if (BN >= (i + 1) * 64 || lrow + i * 64 < BN) *reinterpret_cast<uint4*>(&lds_b[buf][lrow + i * 64][sk]) = rb[i];
     };
 
     // ---- compute state
     const int wgm = wave / WGN, wgn = wave - wgm * WGN;
     const int prow = wgm * WM * 16, crow = wgn * WN * 16;
-    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const int fr = lane & 15;
+    const int fk = ((lane >> 4) ^ ((-(fr >> 2)) & 3)) * 8;     // swizzled chunk of this lane's fragment rows
     f32x4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -163,30 +229,49 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds channels cbase..cbase+3 of pixel (tile pixel i*16 + fr)
+    // ---- epilogue: lane holds channels cbase..cbase+3 of pixel (tile pixel i*16 + fr).  The first pixel's
+    // coordinates come from two divisions, the following ones (+16 pixels each) by carrying.
+    const int cq = (lane >> 4) * 4;
+    float bv[WN][4];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        long q = m0 + prow + i * 16 + fr;
-        if (q >= total_pix) continue;
-        int b = (int)(q % g.Wg);
-        long t2 = q / g.Wg;
-        int a = (int)(t2 % g.Hg);
-        long n = t2 / g.Hg;
-        T* drow = dst + ((n * g.Hd + a * g.ostep + g.ooff_h) * (long)g.Wd + b * g.ostep + g.ooff_w) * g.ldd;
+    for (int j = 0; j < WN; ++j) {
+        const int c = cd0 + crow + j * 16 + cq;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            int cbase = cd0 + crow + j * 16 + (lane >> 4) * 4;
-            if (cbase >= g.Cd) continue;            // Cd % 8 == 0 => a group of 4 is all-in or all-out
-            float v[4];
+        for (int r = 0; r < 4; ++r) bv[j][r] = (bias != nullptr && c < g.Cd) ? bias[c + r] : 0.f;
+    }
+    {
+        int q = m0 + prow + fr;
+        const unsigned qq = q < total_pix ? q : 0;
+        const unsigned t2 = qq / (unsigned)g.Wg;
+        int b = (int)(qq - t2 * g.Wg);
+        int n = (int)(t2 / (unsigned)g.Hg);
+        int a = (int)t2 - n * g.Hg;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[cbase + r] : 0.f);
-            if (ACC) {
-                float o[4];
-                load_pack<T, 4>(drow + cbase, o);
+        for (int i = 0; i < WM; ++i) {
+            if (q < total_pix) {
+                T* drow = dst + (((long)n * g.Hd + a * g.ostep + g.ooff_h) * (long)g.Wd + b * g.ostep + g.ooff_w) * g.ldd;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += o[r];
+                for (int j = 0; j < WN; ++j) {
+                    const int c = cd0 + crow + j * 16 + cq;
+                    if (c >= g.Cd) continue;            // Cd % 8 == 0 => a group of 4 is all-in or all-out
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                    if (ACC) {
+                        float o[4];
+                        load_pack<T, 4>(drow + c, o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += o[r];
+                    }
+                    store_pack<T, 4>(drow + c, v);
+                }
             }
-            store_pack<T, 4>(drow + cbase, v);
+            q += 16;
+            b += 16;
+            while (b >= g.Wg) {
+                b -= g.Wg;
+                if (++a == g.Hg) { a = 0; ++n; }
+            }
         }
     }
 
@@ -209,14 +294,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
                     q2[r] += v * v;
                 }
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[r] += __shfl_xor(s[r], o, 64);
-                    q2[r] += __shfl_xor(q2[r], o, 64);
-                }
+            for (int r = 0; r < 4; ++r) {
+                s[r] = row16_sum(s[r]);
+                q2[r] = row16_sum(q2[r]);
+            }
             if (fr == 0) {
-                const int cl = crow + j * 16 + (lane >> 4) * 4;
+                const int cl = crow + j * 16 + cq;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     atomicAdd(&sacc[cl + r], s[r]);
@@ -238,6 +321,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
 // weight gradient
 // ------------------------------------------------------------------------------------------------
 constexpr int WG_BP = 32;   // pixels per K-step
+constexpr int WG_LDSROW = 40;   // 32 + 8 pad elements per LDS row
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int ldy,
@@ -246,8 +330,8 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const T* __restrict__ x, int
                                                     long slab_pix) {
     using ops = mfma_ops<T>;
     using frag = typename ops::frag;
-    __shared__ __attribute__((aligned(16))) T lds_y[64][LDSROW];   // [co][pixel]
-    __shared__ __attribute__((aligned(16))) T lds_x[64][LDSROW];   // [ci][pixel]
+    __shared__ __attribute__((aligned(16))) T lds_y[64][WG_LDSROW];   // [co][pixel]
+    __shared__ __attribute__((aligned(16))) T lds_x[64][WG_LDSROW];   // [ci][pixel]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int co0 = blockIdx.x * 64;
@@ -350,12 +434,12 @@ void launch_tile(const GeomDev& d, const void* src, const void* wm, const float*
     long pix = (long)d.N * d.Hg * d.Wg;
     int tm = (int)((pix + BM - 1) / BM), tn = (d.Cd + BN - 1) / BN;
     dim3 grid(tm * tn);
-    const bool smallc = d.Cs < BK;       // a 32-wide K step can then cross more than one tap
+    const int mode = d.Cs < BK ? 1 : (d.Cs % BK == 0 ? 2 : 0);
 #define CONV_LAUNCH(ACC_, SM_)                                                                                        \
     hipLaunchKernelGGL((k_conv_mfma<T, WGM, WGN, WM, WN, ACC_, SM_>), grid, dim3(256), 0, st, d, (const T*)src,       \
                        (const T*)wm, bias, (T*)dst, tn)
-    if (accumulate) { if (smallc) CONV_LAUNCH(true, true); else CONV_LAUNCH(true, false); }
-    else { if (smallc) CONV_LAUNCH(false, true); else CONV_LAUNCH(false, false); }
+    if (accumulate) { if (mode == 1) CONV_LAUNCH(true, 1); else if (mode == 2) CONV_LAUNCH(true, 2); else CONV_LAUNCH(true, 0); }
+    else { if (mode == 1) CONV_LAUNCH(false, 1); else if (mode == 2) CONV_LAUNCH(false, 2); else CONV_LAUNCH(false, 0); }
 #undef CONV_LAUNCH
 }
 
@@ -380,7 +464,9 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst) {
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
     if (g.Cs % 8 || g.lds % 8 || g.Cd % 8 || g.ldd % 4) return 0;
-    if ((long)g.N * g.Hs * g.Ws * g.lds >= (1L << 31)) return 0;      // the gather uses 32-bit element offsets
+    // 32-bit byte offsets / buffer descriptors in the gather, 32-bit pixel indices
+    if ((long)g.N * g.Hs * g.Ws * g.lds + (long)(g.Ws + 1) * g.lds >= (1L << 30)) return 0;
+    if ((long)g.N * g.Hg * g.Wg + 256 >= (1L << 31) || (long)g.Cd * g.Kpad >= (1L << 30)) return 0;
     if (!al16(src) || !al16(wm) || (reinterpret_cast<uintptr_t>(dst) & 7)) return 0;
     for (int t = 0; t < g.ntaps; ++t)
         if (g.dh[t] < -1 || g.dh[t] > 1 || g.dw[t] < -1 || g.dw[t] > 1) return 0;
