@@ -42,6 +42,16 @@ __device__ __forceinline__ void store_pack(T* p, const float (&in)[V]) {
     *reinterpret_cast<pack_t<T, V>*>(p) = t;
 }
 
+// split form: issue several raw loads first, convert when the value is consumed (a float array per load
+// in flight would double the registers held across the memory latency)
+template <typename T, int V>
+__device__ __forceinline__ pack_t<T, V> load_raw(const T* p) { return *reinterpret_cast<const pack_t<T, V>*>(p); }
+template <typename T, int V>
+__device__ __forceinline__ void unpack(const pack_t<T, V>& t, float (&out)[V]) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = to_f<T>(t.v[i]);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

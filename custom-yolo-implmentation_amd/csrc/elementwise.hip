@@ -6,6 +6,8 @@
 namespace {
 
 constexpr int TPB = 256;
+constexpr int RS_ROWS = 2;        // pixel rows (independent 16-byte loads per tensor) in flight per thread
+constexpr int RS_MAXBLK = 256 * 8;  // row-strided grids: at most 8 workgroups per CU
 
 template <typename T> __host__ bool vec_ok(const void* p, long ld, int C) {
     constexpr int V = vec_of<T>::N;
@@ -74,7 +76,7 @@ __global__ void k_copy_channels(const T* __restrict__ src, int lds_, T* __restri
 // ---------------------------------------------------------------------------------------------
 // per-channel reductions over pixels: partial[blk][2][C]
 //   MODE 0: (sum y, sum y^2)                      -- BN batch statistics / bias gradient
-//   MODE 1: (sum dz, sum dz*yhat), dz = dout*act'(z), z = y*scale+shift, yhat = (y-mean)*invstd
+//   MODE 1: (sum dz, sum dz*y), dz = dout*act'(z), z = y*scale+shift   (the finalize kernel centres it)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_grad(float z, int act) {
     if (act == 0) return 1.f;
@@ -84,7 +86,7 @@ __device__ __forceinline__ float act_grad(float z, int act) {
 __device__ __forceinline__ float act_fwd(float z, int act) { return act == 0 ? z : z * sigmoidf_(z); }
 
 template <typename T, int V, int MODE>
-__global__ void k_channel_reduce(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_channel_reduce(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                  long npix, int C, int act, float* __restrict__ partial) {
@@ -99,46 +101,56 @@ __global__ void k_channel_reduce(const T* __restrict__ y, int ldy, const T* __re
 #pragma unroll
     for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
     if (active) {
-        float sc[V], sh[V], mu[V], is[V];
+        float sc[V], sh[V];
         if (MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                sc[j] = scale[cg * V + j]; sh[j] = shift[cg * V + j];
-                mu[j] = mean[cg * V + j];  is[j] = invstd[cg * V + j];
-            }
+            for (int j = 0; j < V; ++j) { sc[j] = scale[cg * V + j]; sh[j] = shift[cg * V + j]; }
         }
-        for (long p = (long)blockIdx.x * rpb + r; p < npix; p += (long)gridDim.x * rpb) {
-            float a[V];
-            load_pack<T, V>(y + p * ldy + cg * V, a);
-            if (MODE == 0) {
+        const long step = (long)gridDim.x * rpb;
+        auto one = [&](const pack_t<T, V>& pa, const pack_t<T, V>& pd) {
+            float a[V], d[V];
+            unpack<T, V>(pa, a);
+            if (MODE == 1) unpack<T, V>(pd, d);
 #pragma unroll
-                for (int j = 0; j < V; ++j) { s[j] += a[j]; q[j] += a[j] * a[j]; }
-            } else {
-                float d[V];
-                load_pack<T, V>(dout + p * ldd + cg * V, d);
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
+            for (int j = 0; j < V; ++j) {
+                if (MODE == 0) { s[j] += a[j]; q[j] += a[j] * a[j]; }
+                else {
                     float dz = d[j] * act_grad(a[j] * sc[j] + sh[j], act);
                     s[j] += dz;
-                    q[j] += dz * ((a[j] - mu[j]) * is[j]);
+                    q[j] += dz * a[j];           // raw; k_bn_bwd_finalize turns it into sum(dz*yhat) in double
                 }
             }
+        };
+        long p = (long)blockIdx.x * rpb + r;
+        for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {
+            pack_t<T, V> ra[RS_ROWS], rd[RS_ROWS];
+#pragma unroll
+            for (int k = 0; k < RS_ROWS; ++k) {
+                ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
+                if (MODE == 1) rd[k] = load_raw<T, V>(dout + (p + k * step) * ldd + cg * V);
+            }
+#pragma unroll
+            for (int k = 0; k < RS_ROWS; ++k) one(ra[k], rd[k]);
+        }
+        for (; p < npix; p += step) {
+            pack_t<T, V> pa = load_raw<T, V>(y + p * ldy + cg * V), pd;
+            if (MODE == 1) pd = load_raw<T, V>(dout + p * ldd + cg * V);
+            one(pa, pd);
         }
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) { red[threadIdx.x][j] = s[j]; red[threadIdx.x][V + j] = q[j]; }
     __syncthreads();
-    if (r == 0 && cg < cv) {
-        for (int rr = 1; rr < rpb; ++rr) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                s[j] += red[threadIdx.x + rr * tpr][j];
-                q[j] += red[threadIdx.x + rr * tpr][V + j];
-            }
-        }
-        float* o = partial + (long)blockIdx.x * 2 * C;
-#pragma unroll
-        for (int j = 0; j < V; ++j) { o[cg * V + j] = s[j]; o[C + cg * V + j] = q[j]; }
+    // one thread per (channel group, value): tpr*2V outputs, each the sum over the workgroup's rpb pixel rows
+    // (a single row of threads walking all rows serially cost 10-20 us per workgroup on narrow layers)
+    float* o = partial + (long)blockIdx.x * 2 * C;
+    for (int t = threadIdx.x; t < tpr * 2 * V; t += TPB) {
+        const int cl = t / (2 * V), j = t - cl * 2 * V;
+        float a = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < rpb; ++rr) a += red[rr * tpr + cl][j];
+        const int cgo = blockIdx.y * tpr + cl;
+        if (cgo < cv) o[(j / V) * C + cgo * V + (j % V)] = a;
     }
 }
 
@@ -197,38 +209,49 @@ __global__ void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restr
                 sc[j] = gamma[c] * is[j]; sh[j] = beta[c] - mu[j] * sc[j];
             }
         }
-        for (long p = (long)blockIdx.x * rpb + r; p < npix; p += (long)gridDim.x * rpb) {
-            float a[V];
-            load_pack<T, V>(y + p * ldy + cg * V, a);
-            if (MODE == 0) {
+        const long step = (long)gridDim.x * rpb;
+        auto one = [&](const pack_t<T, V>& pa, const pack_t<T, V>& pd) {
+            float a[V], d[V];
+            unpack<T, V>(pa, a);
+            if (MODE == 1) unpack<T, V>(pd, d);
 #pragma unroll
-                for (int j = 0; j < V; ++j) { s[j] += a[j]; q[j] += a[j] * a[j]; }
-            } else {
-                float d[V];
-                load_pack<T, V>(dout + p * ldd + cg * V, d);
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
+            for (int j = 0; j < V; ++j) {
+                if (MODE == 0) { s[j] += a[j]; q[j] += a[j] * a[j]; }
+                else {
                     float dz = d[j] * act_grad(a[j] * sc[j] + sh[j], act);
                     s[j] += dz;
                     q[j] += dz * ((a[j] - mu[j]) * is[j]);
                 }
             }
+        };
+        long p = (long)blockIdx.x * rpb + r;
+        for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {
+            pack_t<T, V> ra[RS_ROWS], rd[RS_ROWS];
+#pragma unroll
+            for (int k = 0; k < RS_ROWS; ++k) {
+                ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
+                if (MODE == 1) rd[k] = load_raw<T, V>(dout + (p + k * step) * ldd + cg * V);
+            }
+#pragma unroll
+            for (int k = 0; k < RS_ROWS; ++k) one(ra[k], rd[k]);
+        }
+        for (; p < npix; p += step) {
+            pack_t<T, V> pa = load_raw<T, V>(y + p * ldy + cg * V), pd;
+            if (MODE == 1) pd = load_raw<T, V>(dout + p * ldd + cg * V);
+            one(pa, pd);
         }
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) { red[threadIdx.x][j] = s[j]; red[threadIdx.x][V + j] = q[j]; }
     __syncthreads();
-    if (r == 0 && cg < cv) {
-        for (int rr = 1; rr < rpb; ++rr) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                s[j] += red[threadIdx.x + rr * tpr][j];
-                q[j] += red[threadIdx.x + rr * tpr][V + j];
-            }
-        }
-        float* o = acc + (long)(blockIdx.x % BN_REPL) * 2 * C;
-#pragma unroll
-        for (int j = 0; j < V; ++j) { atomicAdd(o + cg * V + j, s[j]); atomicAdd(o + C + cg * V + j, q[j]); }
+    float* o = acc + (long)(blockIdx.x % BN_REPL) * 2 * C;
+    for (int t = threadIdx.x; t < tpr * 2 * V; t += TPB) {
+        const int cl = t / (2 * V), j = t - cl * 2 * V;
+        float a = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < rpb; ++rr) a += red[rr * tpr + cl][j];
+        const int cgo = blockIdx.y * tpr + cl;
+        if (cgo < cv) atomicAdd(o + (j / V) * C + cgo * V + (j % V), a);
     }
 }
 
@@ -376,13 +399,14 @@ __global__ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, co
 // j, j+32, ... of its channel (128-byte coalesced rows), LDS combines the 32 parts; the thread with
 // part 0 gets the totals and returns its channel, the others return -1.  (A one-thread-per-channel
 // loop over 512 partials cost ~95 us per launch, 15 ms per training step.)
-constexpr int FIN_CH = 32, FIN_PARTS = 32;
+constexpr int FIN_CH = 16, FIN_PARTS = 64;
 __device__ __forceinline__ int fin_reduce(const float* __restrict__ partial, int nblk, int C, double& s, double& q) {
     __shared__ double red[2][FIN_PARTS][FIN_CH + 1];
     const int cl = threadIdx.x & (FIN_CH - 1), part = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cl;
     double ls = 0.0, lq = 0.0;
     if (c < C)
+#pragma unroll 8
         for (int b = part; b < nblk; b += FIN_PARTS) {
             ls += partial[(long)b * 2 * C + c];
             lq += partial[(long)b * 2 * C + C + c];
@@ -439,6 +463,7 @@ __global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, f
     double s, q;
     const int c = fin_reduce(partial, nblk, C, s, q);
     if (c < 0) return;
+    q = (double)invstd[c] * (q - (double)mean[c] * s);      // partial rows hold sum(dz*y): -> sum(dz*yhat)
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     // dy = k0*(dz - c1 - yhat*c2), yhat = (y-mean)*invstd  ==  A*dz + B*y + D  (three constants per channel)
@@ -456,11 +481,11 @@ __global__ void k_sum_finalize(const float* __restrict__ partial, int nblk, int 
 
 // out = act(y*scale + shift) (+ res)
 template <typename T, int V>
-__global__ void k_bn_act_fwd(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bn_act_fwd(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                              const float* __restrict__ shift, const T* __restrict__ res, int ldr,
                              T* __restrict__ out, int ldo, long npix, int cv, int act) {
     // row-strided: a thread keeps ONE channel group (its scale/shift live in registers) and walks pixels;
-    // no per-element index division, two pixels in flight per iteration
+    // no per-element index division, RS_ROWS pixels (loads) in flight per iteration
     const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
     const int r = threadIdx.x / tpr;
     const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
@@ -469,78 +494,84 @@ __global__ void k_bn_act_fwd(const T* __restrict__ y, int ldy, const float* __re
 #pragma unroll
     for (int j = 0; j < V; ++j) { sc[j] = scale[cg * V + j]; sh[j] = shift[cg * V + j]; }
     const long step = (long)gridDim.x * rpb;
-    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
-        const long p2 = p + step;
-        const bool two = p2 < npix;
-        float a[V], b[V];
-        load_pack<T, V>(y + p * ldy + cg * V, a);
-        if (two) load_pack<T, V>(y + p2 * ldy + cg * V, b);
+    auto one = [&](long p, const pack_t<T, V>& pa, const pack_t<T, V>& pt) {
+        float a[V], t[V];
+        unpack<T, V>(pa, a);
+        if (res) unpack<T, V>(pt, t);
 #pragma unroll
-        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], act);
-        if (res) {
-            float t[V];
-            load_pack<T, V>(res + p * ldr + cg * V, t);
-#pragma unroll
-            for (int j = 0; j < V; ++j) a[j] += t[j];
-        }
+        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], act) + (res ? t[j] : 0.f);
         store_pack<T, V>(out + p * ldo + cg * V, a);
-        if (two) {
+    };
+    long p = (long)blockIdx.x * rpb + r;
+    for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {       // RS_ROWS loads in flight, no bounds tests
+        pack_t<T, V> ra[RS_ROWS], rt[RS_ROWS];
 #pragma unroll
-            for (int j = 0; j < V; ++j) b[j] = act_fwd(b[j] * sc[j] + sh[j], act);
-            if (res) {
-                float t[V];
-                load_pack<T, V>(res + p2 * ldr + cg * V, t);
-#pragma unroll
-                for (int j = 0; j < V; ++j) b[j] += t[j];
-            }
-            store_pack<T, V>(out + p2 * ldo + cg * V, b);
+        for (int k = 0; k < RS_ROWS; ++k) {
+            ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
+            if (res) rt[k] = load_raw<T, V>(res + (p + k * step) * ldr + cg * V);
         }
+#pragma unroll
+        for (int k = 0; k < RS_ROWS; ++k) one(p + k * step, ra[k], rt[k]);
+    }
+    for (; p < npix; p += step) {
+        pack_t<T, V> pa = load_raw<T, V>(y + p * ldy + cg * V), pt;
+        if (res) pt = load_raw<T, V>(res + p * ldr + cg * V);
+        one(p, pa, pt);
     }
 }
 
 // dy = k0*(dz - c1 - yhat*c2);  eval-style (coef == null): dy = scale*dz
 template <typename T, int V>
-__global__ void k_bn_act_bwd_apply(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bn_act_bwd_apply(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                    const float* __restrict__ coef, T* __restrict__ dy, int lddy,
                                    long npix, int C, int act) {
-    // dy = A*dz + B*y + D with (A, B, D) = coef rows from k_bn_bwd_finalize; frozen statistics: (scale, 0, 0)
+    // dy = A*dz + B*y + D with (A, B, D) = coef rows from k_bn_bwd_finalize; frozen statistics: (scale, 0, 0).
+    // The five per-channel constants of the workgroup's channels sit in LDS ([5][tpr*V] floats, dynamic) and are
+    // read at use: forty live coefficient registers per thread would halve the occupancy of a pure streaming kernel.
+    extern __shared__ float cf[];
     const int cv = C / V;
     const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    const int cw = tpr * V;                                  // channels of this workgroup
+    for (int t = threadIdx.x; t < cw; t += TPB) {
+        const int c = blockIdx.y * cw + t;
+        const bool in = c < C;
+        cf[t] = in ? scale[c] : 0.f;
+        cf[cw + t] = in ? shift[c] : 0.f;
+        cf[2 * cw + t] = in ? (coef ? coef[c] : scale[c]) : 0.f;
+        cf[3 * cw + t] = (in && coef) ? coef[C + c] : 0.f;
+        cf[4 * cw + t] = (in && coef) ? coef[2 * C + c] : 0.f;
+    }
+    __syncthreads();
     const int r = threadIdx.x / tpr;
-    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    const int cl = threadIdx.x - r * tpr;
+    const int cg = blockIdx.y * tpr + cl;
     if (r >= rpb || cg >= cv) return;
-    float sc[V], sh[V], cA[V], cB[V], cD[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-        const int c = cg * V + j;
-        sc[j] = scale[c]; sh[j] = shift[c];
-        cA[j] = coef ? coef[c] : scale[c];
-        cB[j] = coef ? coef[C + c] : 0.f;
-        cD[j] = coef ? coef[2 * C + c] : 0.f;
-    }
+    const float* my = cf + cl * V;
     const long step = (long)gridDim.x * rpb;
-    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
-        const long p2 = p + step;
-        const bool two = p2 < npix;
-        float a[V], d[V], a2[V], d2[V];
-        load_pack<T, V>(y + p * ldy + cg * V, a);
-        load_pack<T, V>(dout + p * ldd + cg * V, d);
-        if (two) {
-            load_pack<T, V>(y + p2 * ldy + cg * V, a2);
-            load_pack<T, V>(dout + p2 * ldd + cg * V, d2);
-        }
+    auto one = [&](long p, const pack_t<T, V>& pa, const pack_t<T, V>& pd) {
+        float a[V], d[V];
+        unpack<T, V>(pa, a);
+        unpack<T, V>(pd, d);
 #pragma unroll
-        for (int j = 0; j < V; ++j) d[j] = cA[j] * (d[j] * act_grad(a[j] * sc[j] + sh[j], act)) + cB[j] * a[j] + cD[j];
+        for (int j = 0; j < V; ++j)
+            d[j] = my[2 * cw + j] * (d[j] * act_grad(a[j] * my[j] + my[cw + j], act)) + my[3 * cw + j] * a[j] + my[4 * cw + j];
         store_pack<T, V>(dy + p * lddy + cg * V, d);
-        if (two) {
+    };
+    long p = (long)blockIdx.x * rpb + r;
+    for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {
+        pack_t<T, V> ra[RS_ROWS], rd[RS_ROWS];
 #pragma unroll
-            for (int j = 0; j < V; ++j)
-                d2[j] = cA[j] * (d2[j] * act_grad(a2[j] * sc[j] + sh[j], act)) + cB[j] * a2[j] + cD[j];
-            store_pack<T, V>(dy + p2 * lddy + cg * V, d2);
+        for (int k = 0; k < RS_ROWS; ++k) {
+            ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
+            rd[k] = load_raw<T, V>(dout + (p + k * step) * ldd + cg * V);
         }
+#pragma unroll
+        for (int k = 0; k < RS_ROWS; ++k) one(p + k * step, ra[k], rd[k]);
     }
+    for (; p < npix; p += step)
+        one(p, load_raw<T, V>(y + p * ldy + cg * V), load_raw<T, V>(dout + p * ldd + cg * V));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -676,12 +707,15 @@ __global__ void k_upsample2x_bwd(const T* __restrict__ dout, int ldd, T* __restr
     }
 }
 
-// grid of a row-strided kernel: x walks pixel rows (2 per thread per iteration), y covers channel groups > 256
+// grid of a row-strided kernel: x walks pixel rows (RS_ROWS per thread per iteration), y covers channel groups >
+// 256.  At most RS_MAXBLK workgroups (all resident at once: no partial last round), and every workgroup gets
+// the same number of iterations.
 inline dim3 rs_grid(long npix, int cv) {
     int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
-    long gx = (npix + 2L * rpb - 1) / (2L * rpb);
-    if (gx > 256 * 12) gx = 256 * 12;
-    if (gx < 1) gx = 1;
+    long units = (npix + (long)RS_ROWS * rpb - 1) / ((long)RS_ROWS * rpb);
+    if (units < 1) units = 1;
+    long iters = (units + RS_MAXBLK - 1) / RS_MAXBLK;
+    long gx = (units + iters - 1) / iters;
     return dim3((unsigned)gx, (unsigned)ceil_div(cv, tpr));
 }
 
@@ -758,10 +792,16 @@ int yolo_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, long 
 
 // number of partial blocks yolo_bn_stats / yolo_bn_act_bwd_reduce will write for this problem
 int yolo_reduce_nblk(long npix, int C) {
-    long want = npix / 64;
-    if (want < 1) want = 1;
-    if (want > 512) want = 512;
-    return (int)want;
+    // one partial row per workgroup; same balanced sizing as the other row-strided kernels (<= 1024 workgroups)
+    int cv = C / 8 > 0 ? C / 8 : 1;
+    int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    long units = (npix + (long)RS_ROWS * rpb - 1) / ((long)RS_ROWS * rpb);
+    if (units < 1) units = 1;
+    long cap = npix / 32;              // keep the partial rows (2*C floats each) well below the tensor's own bytes
+    if (cap > 1024) cap = 1024;
+    if (cap < 1) cap = 1;
+    long iters = (units + cap - 1) / cap;
+    return (int)((units + iters - 1) / iters);
 }
 
 static int launch_reduce(int mode, const void* y, int ldy, const void* dout, int ldd, const float* scale,
@@ -842,7 +882,8 @@ int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, con
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(dout, ldd, C) && vec_ok<T>(dy, lddy, C);
         PICK_V(T, ok, {
             int cv = C / V;
-            hipLaunchKernelGGL((k_bn_act_bwd_apply<T, V>), rs_grid(npix, cv), dim3(TPB), 0, st, (const T*)dout,
+            const int tpr = cv < TPB ? cv : TPB;
+            hipLaunchKernelGGL((k_bn_act_bwd_apply<T, V>), rs_grid(npix, cv), dim3(TPB), 5 * tpr * V * sizeof(float), st, (const T*)dout,
                                ldd, (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, npix, C, act);
         });
     });
