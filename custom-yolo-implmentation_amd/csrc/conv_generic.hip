@@ -423,7 +423,9 @@ int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw
     int rc = hip_status(hipMemsetAsync(dwp, 0, (size_t)Cout * Kpad * sizeof(float), st));
     if (rc) return rc;
     if (algo != 1 && mfma_wgrad_eligible(Cin, Cout, ldx, ldy, dtype, x, dy)) {
-        if (algo == 3)   // first design (per-tap workgroups, LDS-transposed tiles), kept for A/B runs
+        // the second design addresses through 32-bit buffer offsets: tensors of 2^30 elements or more take the first
+        const bool big = (long)N * H * W * ldx + (long)(W + 1) * ldx >= (1L << 30) || (long)N * OH * OW * ldy >= (1L << 30);
+        if (algo == 3 || big)   // first design (per-tap workgroups, LDS-transposed tiles), also kept for A/B runs
             return mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
         return mfma_wgrad2_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
     }

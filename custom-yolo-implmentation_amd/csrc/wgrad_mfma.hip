@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct mm;
 template <> struct mm<bf16_t> {
@@ -71,32 +72,56 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
 #pragma unroll
             for (int j = 0; j < TCI; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // loader roles: dY: pixel j = tid>>3 (0..31), channel chunk tid&7;  X: chunk ids tid + 256*r
-    uint4 ry, rx[XR];
-    auto gload = [&](long pi) {
+    // ---- loader.  Both tensors are read through buffer descriptors: a thread's chunk has a FIXED byte offset
+    // inside the patch (voffset), the patch origin is one scalar (soffset), and a chunk outside the image or
+    // the channel range gets a voffset past the descriptor's range, which reads as zero.  The descriptor of X
+    // starts one row and one pixel before the tensor so the origin of a border patch is never negative.
+    // Patch coordinates (n, bh, bw) advance by carrying -- no division in the loop.  (host: sizes < 2^30 elements)
+    const int xshift = (a.W + 1) * a.ldx;
+    const __amdgpu_buffer_rsrc_t rsx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x) - xshift, 0, (a.N * a.H * a.W * a.ldx + xshift) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy), 0, a.N * a.OH * a.OW * a.ldy * 2, 0x00020000);
+    const int yj = tid >> 3, ych = (tid & 7) * 8;            // dY: pixel yj (0..31) of the patch, channel chunk
+    const int yr = yj >> 3, ycol = yj & 7;
+    const int yvoff = (bco + ych < a.Cout) ? ((yr * a.OW + ycol) * a.ldy + bco + ych) * 2 : (int)0x80000000;
+    int xpr[XR], xpc[XR], xvoff[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+        const int id = tid + 256 * r;
+        const int px = id >> 3, ch = (id & 7) * 8;
+        xpr[r] = px / PW;
+        xpc[r] = px - xpr[r] * PW;
+        xvoff[r] = (id < XCH && bci + ch < a.Cin) ? ((xpr[r] * a.W + xpc[r]) * a.ldx + bci + ch) * 2 : (int)0x80000000;
+    }
+    int pn, pbh, pbw;                                        // coordinates of the patch gload fetches next
+    {
         const int per_img = a.pbh * a.pbw;
-        const long n = pi / per_img;
-        const int rem = (int)(pi - n * per_img);
-        const int bh = rem / a.pbw, bw = rem - bh * a.pbw;
-        const int oh0 = bh * 4, ow0 = bw * 8;
+        pn = (int)(p_begin / per_img);
+        const int rem = (int)(p_begin - (long)pn * per_img);
+        pbh = rem / a.pbw;
+        pbw = rem - pbh * a.pbw;
+    }
+    uint4 ry, rx[XR];
+    auto gload = [&]() {
+        const int oh0 = pbh * 4, ow0 = pbw * 8;
+        const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
         {
-            const int j = tid >> 3, ch = (tid & 7) * 8;
-            const int oh = oh0 + (j >> 3), ow = ow0 + (j & 7);
-            ry = make_uint4(0, 0, 0, 0);
-            if (oh < a.OH && ow < a.OW && bco + ch < a.Cout)
-                ry = *reinterpret_cast<const uint4*>(dy + ((n * a.OH + oh) * (long)a.OW + ow) * a.ldy + bco + ch);
+            const bool ok = oh0 + yr < a.OH && ow0 + ycol < a.OW;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok ? yvoff : (int)0x80000000,
+                                                                  ((pn * a.OH + oh0) * a.OW + ow0) * a.ldy * 2, 0);
+            ry = make_uint4(v.x, v.y, v.z, v.w);
         }
+        const int xsoff = (((pn * a.H + ih0) * a.W + iw0) * a.ldx + xshift) * 2;
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
-            const int id = tid + 256 * r;
-            rx[r] = make_uint4(0, 0, 0, 0);
-            if (id < XCH) {
-                const int px = id >> 3, ch = (id & 7) * 8;
-                const int pr = px / PW, pc = px - pr * PW;
-                const int ih = oh0 * S - PAD + pr, iw = ow0 * S - PAD + pc;
-                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && bci + ch < a.Cin)
-                    rx[r] = *reinterpret_cast<const uint4*>(x + ((n * a.H + ih) * (long)a.W + iw) * a.ldx + bci + ch);
-            }
+            const bool ok = (unsigned)(ih0 + xpr[r]) < (unsigned)a.H && (unsigned)(iw0 + xpc[r]) < (unsigned)a.W;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvoff[r] : (int)0x80000000, xsoff, 0);
+            rx[r] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        if (++pbw == a.pbw) {
+            pbw = 0;
+            if (++pbh == a.pbh) { pbh = 0; ++pn; }
         }
     };
     auto lstore = [&]() {
@@ -109,12 +134,12 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
     };
 
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
-    if (p_begin < p_end) gload(p_begin);
+    if (p_begin < p_end) gload();
     for (long pi = p_begin; pi < p_end; ++pi) {
         __syncthreads();
         lstore();
         __syncthreads();
-        if (pi + 1 < p_end) gload(pi + 1);
+        if (pi + 1 < p_end) gload();
         // A fragments (dY^T): rows = co, k = patch pixel 8g + j  ->  LDS pixel rows 8g+q and 8g+4+q
         typename mm<T>::frag fa[TCO];
 #pragma unroll
