@@ -107,7 +107,8 @@ class KernelTimer:
                 _, e0, e1, fl, by = self.rec[i]
                 ms = e0.elapsed_time(e1)
                 rows.append((ms, name, shapes, ints, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0))
-            for ms, name, shapes, ints, tf, gbs in sorted(rows, key=lambda r: -r[0])[:40]:
+            top = len(rows) if os.environ.get("BENCH_VERBOSE") == "2" else 40
+            for ms, name, shapes, ints, tf, gbs in sorted(rows, key=lambda r: -r[0])[:top]:
                 print(f"[detail] {1e3 * ms:8.1f} us {name:14s} {tf:7.1f} TF/s {gbs:7.0f} GB/s {shapes} {ints}", file=sys.stderr)
         groups = {}
         for grp, e0, e1, fl, by in self.rec:

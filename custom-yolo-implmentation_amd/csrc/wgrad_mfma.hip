@@ -29,7 +29,9 @@ template <> struct mm<f16_t> {
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int LDC = 72;      // LDS row (one pixel): 64 channels + 8 pad, 144 bytes
+// LDS row (one pixel) of a T*32-channel tile: pad so that the four pixel rows of a transposing read land on
+// different banks (row stride in banks mod 64: 32 ch -> 16, 64 -> 36, 96 -> 48, 128 -> 8)
+constexpr int ldc_of(int t) { return t == 2 ? 72 : t == 4 ? 144 : t * 32; }
 
 struct WgArgs {
     int N, H, W, Cin, ldx, OH, OW, Cout, ldy, Kpad;
@@ -51,11 +53,14 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
                                                 float* __restrict__ dwp) {
     constexpr int PAD = KS / 2;
     constexpr int PH = 3 * S + KS, PW = 7 * S + KS;          // X patch (with halo) for 4 x 8 outputs
-    constexpr int XCH = PH * PW * 8;                          // 16-byte chunks in the X patch (64 channels)
+    constexpr int LDY = ldc_of(TCO), LDX = ldc_of(TCI);
+    constexpr int CPY = TCO * 4, CPX = TCI * 4;               // 16-byte chunks per pixel (dY / X tile)
+    constexpr int YCH = 32 * CPY, YR = (YCH + 255) / 256;     // dY chunks per patch / per thread
+    constexpr int XCH = PH * PW * CPX;                        // 16-byte chunks in the X patch
     constexpr int XR = (XCH + 255) / 256;                     // chunks per thread
     constexpr int NT = KS * KS;
-    __shared__ __attribute__((aligned(16))) T ys[32 * LDC];
-    __shared__ __attribute__((aligned(16))) T xs[PH * PW * LDC];
+    __shared__ __attribute__((aligned(16))) T ys[32 * LDY];
+    __shared__ __attribute__((aligned(16))) T xs[PH * PW * LDX];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wi = wave & 1;
@@ -82,14 +87,20 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x) - xshift, 0, (a.N * a.H * a.W * a.ldx + xshift) * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy), 0, a.N * a.OH * a.OW * a.ldy * 2, 0x00020000);
-    const int yj = tid >> 3, ych = (tid & 7) * 8;            // dY: pixel yj (0..31) of the patch, channel chunk
-    const int yr = yj >> 3, ycol = yj & 7;
-    const int yvoff = (bco + ych < a.Cout) ? ((yr * a.OW + ycol) * a.ldy + bco + ych) * 2 : (int)0x80000000;
+    int yrow[YR], ycol[YR], yvoff[YR];                       // dY chunk: pixel (row, col) of the 4x8 patch + channel chunk
+#pragma unroll
+    for (int r = 0; r < YR; ++r) {
+        const int id = tid + 256 * r;
+        const int j = id / CPY, ch = (id - j * CPY) * 8;
+        yrow[r] = j >> 3;
+        ycol[r] = j & 7;
+        yvoff[r] = (id < YCH && bco + ch < a.Cout) ? ((yrow[r] * a.OW + ycol[r]) * a.ldy + bco + ch) * 2 : (int)0x80000000;
+    }
     int xpr[XR], xpc[XR], xvoff[XR];
 #pragma unroll
     for (int r = 0; r < XR; ++r) {
         const int id = tid + 256 * r;
-        const int px = id >> 3, ch = (id & 7) * 8;
+        const int px = id / CPX, ch = (id - px * CPX) * 8;
         xpr[r] = px / PW;
         xpc[r] = px - xpr[r] * PW;
         xvoff[r] = (id < XCH && bci + ch < a.Cin) ? ((xpr[r] * a.W + xpc[r]) * a.ldx + bci + ch) * 2 : (int)0x80000000;
@@ -102,15 +113,16 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         pbh = rem / a.pbw;
         pbw = rem - pbh * a.pbw;
     }
-    uint4 ry, rx[XR];
+    uint4 ry[YR], rx[XR];
     auto gload = [&]() {
         const int oh0 = pbh * 4, ow0 = pbw * 8;
         const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
-        {
-            const bool ok = oh0 + yr < a.OH && ow0 + ycol < a.OW;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok ? yvoff : (int)0x80000000,
-                                                                  ((pn * a.OH + oh0) * a.OW + ow0) * a.ldy * 2, 0);
-            ry = make_uint4(v.x, v.y, v.z, v.w);
+        const int ysoff = ((pn * a.OH + oh0) * a.OW + ow0) * a.ldy * 2;
+#pragma unroll
+        for (int r = 0; r < YR; ++r) {
+            const bool ok = oh0 + yrow[r] < a.OH && ow0 + ycol[r] < a.OW;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok ? yvoff[r] : (int)0x80000000, ysoff, 0);
+            ry[r] = make_uint4(v.x, v.y, v.z, v.w);
         }
         const int xsoff = (((pn * a.H + ih0) * a.W + iw0) * a.ldx + xshift) * 2;
 #pragma unroll
@@ -125,11 +137,15 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         }
     };
     auto lstore = [&]() {
-        *reinterpret_cast<uint4*>(ys + (tid >> 3) * LDC + (tid & 7) * 8) = ry;
+#pragma unroll
+        for (int r = 0; r < YR; ++r) {
+            const int id = tid + 256 * r;
+            if (id < YCH) *reinterpret_cast<uint4*>(ys + (id / CPY) * LDY + (id % CPY) * 8) = ry[r];
+        }
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
             const int id = tid + 256 * r;
-            if (id < XCH) *reinterpret_cast<uint4*>(xs + (id >> 3) * LDC + (id & 7) * 8) = rx[r];
+            if (id < XCH) *reinterpret_cast<uint4*>(xs + (id / CPX) * LDX + (id % CPX) * 8) = rx[r];
         }
     };
 
@@ -144,19 +160,19 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         typename mm<T>::frag fa[TCO];
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
-            const T* p = ys + (8 * g + q) * LDC + (wc * TCO + i) * 16 + c4;
-            fa[i] = tr_frag<T>(p, p + 4 * LDC);
+            const T* p = ys + (8 * g + q) * LDY + (wc * TCO + i) * 16 + c4;
+            fa[i] = tr_frag<T>(p, p + 4 * LDY);
         }
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
                 // output pixel (row g, col q | q+4) reads X patch pixel (g*S + kh, col*S + kw)
-                const T* base = xs + ((g * S + kh) * PW + q * S + kw) * LDC + c4;
+                const T* base = xs + ((g * S + kh) * PW + q * S + kw) * LDX + c4;
 #pragma unroll
                 for (int j = 0; j < TCI; ++j) {
                     const T* p = base + (wi * TCI + j) * 16;
-                    typename mm<T>::frag fb = tr_frag<T>(p, p + 4 * S * LDC);
+                    typename mm<T>::frag fb = tr_frag<T>(p, p + 4 * S * LDX);
 #pragma unroll
                     for (int i = 0; i < TCO; ++i) acc[kh * KS + kw][i][j] = mm<T>::mma(fa[i], fb, acc[kh * KS + kw][i][j]);
                 }
@@ -185,10 +201,10 @@ void launch(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStrea
     WgArgs b = a;
     // each workgroup ends with KS*KS*(32*TCO)*(32*TCI) fp32 atomics (147 KB for a 3x3 64x64 tile): keep the
     // workgroup count at ~2 per CU for 3x3 so that flush stays far below the pixel traffic
-    long want = (KS == 3 ? 512 : 2048) / ((long)cot * cit);
+    long want = (KS == 3 ? 512 : (TCO * TCI > 4 ? 1024 : 2048)) / ((long)cot * cit);
     // ... and give every workgroup at least ~16 patches (3x3) before it flushes: on small maps one-patch
     // workgroups spent 100+ us hammering the same 147 KB with atomics (64->64 3x3 @20x20: 117 us, 8 TFLOP/s)
-    const long min_per = KS == 3 ? 16 : 4;
+    const long min_per = KS == 3 ? 16 : (TCO * TCI > 4 ? 8 : 4);
     if (want > a.npatch / min_per) want = a.npatch / min_per;
     if (want < 1) want = 1;
     b.per_slab = (a.npatch + want - 1) / want;
@@ -198,11 +214,24 @@ void launch(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStrea
 
 template <typename T, int KS, int S>
 void launch_tiles(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStream_t st) {
-    const bool bigo = a.Cout > 32, bigi = a.Cin > 32;
-    if (bigo && bigi) launch<T, KS, S, 2, 2>(a, x, dy, dwp, st);
-    else if (bigo) launch<T, KS, S, 2, 1>(a, x, dy, dwp, st);
-    else if (bigi) launch<T, KS, S, 1, 2>(a, x, dy, dwp, st);
-    else launch<T, KS, S, 1, 1>(a, x, dy, dwp, st);
+    if constexpr (KS == 1) {
+        // one tap: the accumulators of a (32*TCO x 32*TCI) tile are TCO*TCI*4 registers, so a workgroup can own
+        // up to 128 x 128 of (co, ci) and X / dY are each read once for layers up to 128 channels
+        const int to = a.Cout > 96 ? 4 : a.Cout > 64 ? 3 : a.Cout > 32 ? 2 : 1;
+        const int ti = a.Cin > 96 ? 4 : a.Cin > 64 ? 3 : a.Cin > 32 ? 2 : 1;
+#define WG_CASE(TO_, TI_) if (to == TO_ && ti == TI_) return launch<T, 1, 1, TO_, TI_>(a, x, dy, dwp, st)
+        WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(1, 3); WG_CASE(1, 4);
+        WG_CASE(2, 1); WG_CASE(2, 2); WG_CASE(2, 3); WG_CASE(2, 4);
+        WG_CASE(3, 1); WG_CASE(3, 2); WG_CASE(3, 3); WG_CASE(3, 4);
+        WG_CASE(4, 1); WG_CASE(4, 2); WG_CASE(4, 3); WG_CASE(4, 4);
+#undef WG_CASE
+    } else {
+        const bool bigo = a.Cout > 32, bigi = a.Cin > 32;
+        if (bigo && bigi) launch<T, KS, S, 2, 2>(a, x, dy, dwp, st);
+        else if (bigo) launch<T, KS, S, 2, 1>(a, x, dy, dwp, st);
+        else if (bigi) launch<T, KS, S, 1, 2>(a, x, dy, dwp, st);
+        else launch<T, KS, S, 1, 1>(a, x, dy, dwp, st);
+    }
 }
 
 template <typename T>

@@ -109,11 +109,18 @@ def test_bf16_autocast_step_vs_fp32_oracle(res, n):
           f"preds {_rel(preds, p_ref):.2e} grad {e_g:.2e} | CPU-bf16-autocast vs fp32 oracle: total {r_tot:.2e} "
           f"dfl {r_dfl:.2e} cls {r_cls:.2e} preds {_rel(p16, p_ref):.2e}")
     # bf16 rounding noise is inherent to the precision (the reference's own CPU bf16 path moves preds by
-    # ~1e-1 max-rel here, and one GT re-assigned to a neighbouring anchor moves mean DFL by percents with
-    # 3-4 GTs per image): the HIP path must stay in the same band as that path
-    for e, r in ((e_tot, r_tot), (e_dfl, r_dfl), (e_cls, r_cls)):
-        assert e < max(4 * r, 5e-2), (e, r)
+    # ~1e-1 max-rel here).  The loss is a chaotic function of it at this size -- one GT re-assigned to a
+    # neighbouring anchor moves a mean over ~7 positives by >10 % -- and the batch statistics are summed with float
+    # atomics, so the HIP value moves a little from run to run: (1) the predictions must stay in the band of the
+    # CPU bf16 path, (2) the loss kernels must agree tightly with the oracle's loss evaluated ON THE SAME
+    # predictions, (3) the cross-precision loss only gets a sanity band.
     assert _rel(preds, p_ref) < 2 * _rel(p16, p_ref) + 1e-2
+    with torch.no_grad():
+        t_same, d_same, c_same = ol.dfl_qfl_loss(preds.detach().float().cpu(), gts, a.float().cpu(), s.float().cpu(), 80)
+    assert abs(ld["total_loss"] - float(t_same)) / float(t_same) < 5e-3, (ld["total_loss"], float(t_same))
+    assert abs(ld["cls_loss"] - float(c_same)) / float(c_same) < 5e-3 and abs(ld["box_loss"] - float(d_same)) / float(d_same) < 5e-3
+    for e, r in ((e_tot, r_tot), (e_dfl, r_dfl), (e_cls, r_cls)):
+        assert e < max(4 * r, 0.2), (e, r)
 
 
 def test_batched_weight_packing_equals_per_layer_packing():
