@@ -11,8 +11,9 @@ int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst,
                      int accumulate, int dtype, hipStream_t st);
 int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const void* x, const void* dy);
-int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W,
-                       int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
+int mfma_wgrad2_slabs(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k);
+int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* part, void* dw_oihw, int dw_dtype, int Kpad,
+                       int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
 int mfma_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W,
                       int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
 
@@ -414,33 +415,63 @@ int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int ld
     return YOLO_OK;
 }
 
-// dwp[Cout][Kpad] fp32 (forward-packed order) = sum over pixels; caller unpacks with yolo_conv_unpack_wgrad.
-// The buffer is zeroed here (the kernels accumulate with atomics over pixel slabs).
-int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dwp, int N, int H, int W, int Cin,
-                      int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st) {
+// Which weight-gradient kernel a call takes: 2 = MFMA, per-slab partial matrices + reduce (the product path),
+// 3 = first MFMA design (atomics into one matrix; A/B runs and tensors >= 2^30 elements), 1 = generic.
+static int wgrad_path(const void* x, int ldx, const void* dy, int ldy, int N, int H, int W, int Cin, int OH, int OW,
+                      int Cout, int dtype, int algo) {
+    if (algo != 1 && mfma_wgrad_eligible(Cin, Cout, ldx, ldy, dtype, x, dy)) {
+        const bool big = (long)N * H * W * ldx + (long)(W + 1) * ldx >= (1L << 30) || (long)N * OH * OW * ldy >= (1L << 30);
+        return (algo == 3 || big || (long)N * OH * OW == 0) ? 3 : 2;
+    }
+    return 1;
+}
+
+// fp32 scratch elements yolo_conv2d_wgrad needs for these arguments
+long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy, int N, int H, int W, int Cin, int OH,
+                                int OW, int Cout, int k, int stride, int dtype, int algo) {
+    if (!supported(k, stride)) return 0;
+    const int Kpad = round_up32(k * k * Cin);
+    long mats = 1;
+    if (wgrad_path(x, ldx, dy, ldy, N, H, W, Cin, OH, OW, Cout, dtype, algo) == 2)
+        mats = mfma_wgrad2_slabs(Kpad, N, H, W, Cin, OH, OW, Cout, k);
+    return mats * Cout * Kpad;
+}
+
+// dw_oihw[Cout][Cin][k][k] (dw_dtype) = sum over pixels of dy (x) x.  ws: fp32 scratch of
+// yolo_conv2d_wgrad_ws_elems(...) elements, contents undefined before and after (free for reuse on the stream).
+int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws, void* dw_oihw, int dw_dtype, int N,
+                      int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo,
+                      hipStream_t st) {
     if (!supported(k, stride)) return YOLO_ERR_ARG;
-    int K = k * k * Cin, Kpad = round_up32(K);
+    const int K = k * k * Cin, Kpad = round_up32(K);
+    const int path = wgrad_path(x, ldx, dy, ldy, N, H, W, Cin, OH, OW, Cout, dtype, algo);
+    if (path == 2)
+        return mfma_wgrad2_launch(x, ldx, dy, ldy, ws, dw_oihw, dw_dtype, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+    if (algo == 2) return YOLO_ERR_ARG;
+    // single packed matrix accumulated with atomics, then unpacked
+    float* dwp = ws;
     int rc = hip_status(hipMemsetAsync(dwp, 0, (size_t)Cout * Kpad * sizeof(float), st));
     if (rc) return rc;
-    if (algo != 1 && mfma_wgrad_eligible(Cin, Cout, ldx, ldy, dtype, x, dy)) {
-        // the second design addresses through 32-bit buffer offsets: tensors of 2^30 elements or more take the first
-        const bool big = (long)N * H * W * ldx + (long)(W + 1) * ldx >= (1L << 30) || (long)N * OH * OW * ldy >= (1L << 30);
-        if (algo == 3 || big)   // first design (per-tap workgroups, LDS-transposed tiles), also kept for A/B runs
-            return mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
-        return mfma_wgrad2_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+    if (path == 3) {
+        rc = mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+    } else {
+        long nrows = (long)N * OH;
+        long elems = (long)Cout * K;
+        int gx = (int)((elems + 255) / 256);
+        long want_slabs = 4096 / (gx > 0 ? gx : 1);
+        if (want_slabs < 1) want_slabs = 1;
+        if (want_slabs > nrows) want_slabs = nrows;
+        if (want_slabs < 1) want_slabs = 1;
+        int rps = (int)((nrows + want_slabs - 1) / want_slabs);
+        if (rps < 1) rps = 1;
+        int gy = (int)((nrows + rps - 1) / rps);
+        if (gy > 0)
+            YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_wgrad_generic<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, ldx,
+                                                      (const T*)dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, rps));
+        rc = YOLO_LAUNCH_CHECK();
     }
-    if (algo == 2) return YOLO_ERR_ARG;
-    long nrows = (long)N * OH;
-    long elems = (long)Cout * K;
-    int gx = (int)((elems + 255) / 256);
-    long want_slabs = 4096 / (gx > 0 ? gx : 1);
-    if (want_slabs < 1) want_slabs = 1;
-    if (want_slabs > nrows) want_slabs = nrows;
-    int rps = (int)((nrows + want_slabs - 1) / want_slabs);
-    int gy = (int)((nrows + rps - 1) / rps);
-    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_wgrad_generic<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, ldx,
-                                              (const T*)dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, rps));
-    return YOLO_LAUNCH_CHECK();
+    if (rc) return rc;
+    return yolo_conv_unpack_wgrad(dwp, Cout, Cin, k, dw_oihw, dw_dtype, st);
 }
 
 }  // extern "C"

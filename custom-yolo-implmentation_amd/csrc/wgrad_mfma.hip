@@ -8,6 +8,8 @@
 // offsets into the same patch (a [channel][pixel] LDS image would need a misaligned read per tap).
 // MFMA k index j <-> patch pixel (row j/8, col j%8): lane group g = patch row g.
 // Slabs are combined with fp32 atomics into the packed gradient matrix (64-byte runs along ci).
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
                 }
             }
     }
-    // D rows = co ((lane>>4)*4 + r), cols = ci (lane & 15)
+    // D rows = co ((lane>>4)*4 + r), cols = ci (lane & 15); every slab owns one [Cout][Kpad] partial matrix (plain
+    // stores: an atomic flush into one shared matrix ran at ~250 G adds/s and dominated the small layers)
+    float* part = dwp + (long)blockIdx.z * a.Cout * a.Kpad;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -190,71 +194,136 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = bco + (wc * TCO + i) * 16 + g * 4 + r;
-                    if (co < a.Cout) atomicAdd(dwp + (long)co * a.Kpad + t * a.Cin + ci, acc[t][i][j][r]);
+                    if (co < a.Cout) part[(long)co * a.Kpad + t * a.Cin + ci] = acc[t][i][j][r];
                 }
             }
 }
 
-template <typename T, int KS, int S, int TCO, int TCI>
-void launch(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStream_t st) {
-    const int cot = (a.Cout + 32 * TCO - 1) / (32 * TCO), cit = (a.Cin + 32 * TCI - 1) / (32 * TCI);
-    WgArgs b = a;
-    // each workgroup ends with KS*KS*(32*TCO)*(32*TCI) fp32 atomics (147 KB for a 3x3 64x64 tile): keep the
-    // workgroup count at ~2 per CU for 3x3 so that flush stays far below the pixel traffic
-    long want = (KS == 3 ? 512 : (TCO * TCI > 4 ? 1024 : 2048)) / ((long)cot * cit);
-    // ... and give every workgroup at least ~16 patches (3x3) before it flushes: on small maps one-patch
-    // workgroups spent 100+ us hammering the same 147 KB with atomics (64->64 3x3 @20x20: 117 us, 8 TFLOP/s)
-    const long min_per = KS == 3 ? 16 : (TCO * TCI > 4 ? 8 : 4);
+// sum of the slabs' partial matrices -> OIHW gradient in the parameter's dtype (replaces memset + unpack)
+template <typename TO>
+__global__ void k_wgrad_reduce(const float* __restrict__ part, int nslab, int Cout, int Cin, int NT, int Kpad,
+                               TO* __restrict__ dw) {
+    const long total = (long)Cout * Cin * NT;
+    const long slab = (long)Cout * Kpad;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int K = Cin * NT;
+        const int co = (int)(e / K), k = (int)(e - (long)co * K);      // packed order: k = tap*Cin + ci
+        const int t = k / Cin, ci = k - t * Cin;
+        const float* p = part + (long)co * Kpad + k;
+        float a = 0.f;
+#pragma unroll 4
+        for (int s2 = 0; s2 < nslab; ++s2) a += p[s2 * slab];
+        dw[((long)co * Cin + ci) * NT + t] = (TO)a;
+    }
+}
+
+struct WgPlan { int to, ti, cot, cit, nslab; long per_slab; };
+
+// tile and slab choice (shared by the workspace query and the launch)
+WgPlan make_plan(const WgArgs& a, int k) {
+    WgPlan p;
+    // Tuned on MI355X (tools/wg_tune.py, preset-s layer shapes at 32 images):
+    //  1x1: the accumulators of a (32*TCO x 32*TCI) tile are TCO*TCI*4 registers, so a workgroup owns up to 128 x 128
+    //       of (co, ci) and X / dY are each read once for layers up to 128 channels; the widest tile won everywhere.
+    //  3x3: 9 taps x 64 x 64 is 144 accumulator registers; for Cin <= 64 the 64 x 32 tile (72) runs at twice the
+    //       occupancy and wins although dY is then read twice.
+    //  ~2 workgroups per CU overall: more slabs only add partial-matrix traffic.
+    if (k == 1) {
+        p.to = a.Cout > 96 ? 4 : a.Cout > 64 ? 3 : a.Cout > 32 ? 2 : 1;
+        p.ti = a.Cin > 96 ? 4 : a.Cin > 64 ? 3 : a.Cin > 32 ? 2 : 1;
+    } else {
+        p.to = a.Cout > 32 ? 2 : 1;
+        p.ti = a.Cin > 64 ? 2 : 1;
+    }
+    long want_blocks = (k == 1 && p.to * p.ti == 1) ? 1024 : 512;
+    long min_per = 2;
+    if (const char* e = getenv("YOLO_WG_TUNE")) {            // "to,ti,blocks,min_per": tuning runs only
+        int v[4] = {0, 0, 0, 0};
+        sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+        if (v[0] > 0 && (k == 1 || v[0] <= 2)) p.to = v[0];
+        if (v[1] > 0 && (k == 1 || v[1] <= 2)) p.ti = v[1];
+        if (v[2] > 0) want_blocks = v[2];
+        if (v[3] > 0) min_per = v[3];
+    }
+    p.cot = (a.Cout + 32 * p.to - 1) / (32 * p.to);
+    p.cit = (a.Cin + 32 * p.ti - 1) / (32 * p.ti);
+    // ~2 workgroups per CU for 3x3 (144 accumulator registers), ~4 for 1x1; every workgroup ends by storing its
+    // KS*KS*(32*TCO)*(32*TCI) partial sums, so it should see at least a few patches first
+    long want = want_blocks / ((long)p.cot * p.cit);
     if (want > a.npatch / min_per) want = a.npatch / min_per;
     if (want < 1) want = 1;
-    b.per_slab = (a.npatch + want - 1) / want;
-    const int nslab = (int)((a.npatch + b.per_slab - 1) / b.per_slab);
-    hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI>), dim3(cot, cit, nslab), dim3(256), 0, st, b, (const T*)x, (const T*)dy, dwp);
+    p.per_slab = (a.npatch + want - 1) / want;
+    p.nslab = (int)((a.npatch + p.per_slab - 1) / p.per_slab);
+    return p;
+}
+
+template <typename T, int KS, int S, int TCO, int TCI>
+void launch(const WgArgs& a, const WgPlan& p, const void* x, const void* dy, float* part, hipStream_t st) {
+    WgArgs b = a;
+    b.per_slab = p.per_slab;
+    hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI>), dim3(p.cot, p.cit, p.nslab), dim3(256), 0, st, b, (const T*)x,
+                       (const T*)dy, part);
 }
 
 template <typename T, int KS, int S>
-void launch_tiles(const WgArgs& a, const void* x, const void* dy, float* dwp, hipStream_t st) {
+void launch_tiles(const WgArgs& a, const WgPlan& p, const void* x, const void* dy, float* part, hipStream_t st) {
+#define WG_CASE(TO_, TI_) if (p.to == TO_ && p.ti == TI_) return launch<T, KS, S, TO_, TI_>(a, p, x, dy, part, st)
     if constexpr (KS == 1) {
-        // one tap: the accumulators of a (32*TCO x 32*TCI) tile are TCO*TCI*4 registers, so a workgroup can own
-        // up to 128 x 128 of (co, ci) and X / dY are each read once for layers up to 128 channels
-        const int to = a.Cout > 96 ? 4 : a.Cout > 64 ? 3 : a.Cout > 32 ? 2 : 1;
-        const int ti = a.Cin > 96 ? 4 : a.Cin > 64 ? 3 : a.Cin > 32 ? 2 : 1;
-#define WG_CASE(TO_, TI_) if (to == TO_ && ti == TI_) return launch<T, 1, 1, TO_, TI_>(a, x, dy, dwp, st)
         WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(1, 3); WG_CASE(1, 4);
         WG_CASE(2, 1); WG_CASE(2, 2); WG_CASE(2, 3); WG_CASE(2, 4);
         WG_CASE(3, 1); WG_CASE(3, 2); WG_CASE(3, 3); WG_CASE(3, 4);
         WG_CASE(4, 1); WG_CASE(4, 2); WG_CASE(4, 3); WG_CASE(4, 4);
-#undef WG_CASE
     } else {
-        const bool bigo = a.Cout > 32, bigi = a.Cin > 32;
-        if (bigo && bigi) launch<T, KS, S, 2, 2>(a, x, dy, dwp, st);
-        else if (bigo) launch<T, KS, S, 2, 1>(a, x, dy, dwp, st);
-        else if (bigi) launch<T, KS, S, 1, 2>(a, x, dy, dwp, st);
-        else launch<T, KS, S, 1, 1>(a, x, dy, dwp, st);
+        WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(2, 1); WG_CASE(2, 2);
     }
+#undef WG_CASE
 }
 
 template <typename T>
-int launch_ks(const WgArgs& a, int k, int stride, const void* x, const void* dy, float* dwp, hipStream_t st) {
-    if (k == 1 && stride == 1) launch_tiles<T, 1, 1>(a, x, dy, dwp, st);
-    else if (k == 3 && stride == 1) launch_tiles<T, 3, 1>(a, x, dy, dwp, st);
-    else if (k == 3 && stride == 2) launch_tiles<T, 3, 2>(a, x, dy, dwp, st);
+int launch_ks(const WgArgs& a, const WgPlan& p, int k, int stride, const void* x, const void* dy, float* part,
+              hipStream_t st) {
+    if (k == 1 && stride == 1) launch_tiles<T, 1, 1>(a, p, x, dy, part, st);
+    else if (k == 3 && stride == 1) launch_tiles<T, 3, 1>(a, p, x, dy, part, st);
+    else if (k == 3 && stride == 2) launch_tiles<T, 3, 2>(a, p, x, dy, part, st);
     else return YOLO_ERR_ARG;
     return YOLO_LAUNCH_CHECK();
 }
 
-}  // namespace
-
-// dwp (zeroed by the caller) += packed gradient; same eligibility as the first design (mfma_wgrad_eligible)
-int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W, int Cin,
-                       int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st) {
+WgArgs make_args(int ldx, int ldy, int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout) {
     WgArgs a;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.OH = OH; a.OW = OW; a.Cout = Cout; a.ldy = ldy; a.Kpad = Kpad;
     a.pbh = (OH + 3) / 4; a.pbw = (OW + 7) / 8;
     a.npatch = (long)N * a.pbh * a.pbw;
     a.per_slab = 0;
-    if (a.npatch == 0) return YOLO_OK;
-    if (dtype == YOLO_BF16) return launch_ks<bf16_t>(a, k, stride, x, dy, dwp, st);
-    if (dtype == YOLO_F16) return launch_ks<f16_t>(a, k, stride, x, dy, dwp, st);
-    return YOLO_ERR_DTYPE;
+    return a;
+}
+
+}  // namespace
+
+// number of [Cout][Kpad] fp32 partial matrices the launch below writes (same eligibility as the first design)
+int mfma_wgrad2_slabs(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k) {
+    WgArgs a = make_args(0, 0, Kpad, N, H, W, Cin, OH, OW, Cout);
+    if (a.npatch == 0) return 1;
+    return make_plan(a, k).nslab;
+}
+
+// part[nslab][Cout][Kpad] (fp32 scratch, need not be zeroed) <- per-slab partial gradients, then
+// dw_oihw[Cout][Cin][k][k] (dw_dtype) <- their sum
+int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* part, void* dw_oihw, int dw_dtype, int Kpad,
+                       int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st) {
+    WgArgs a = make_args(ldx, ldy, Kpad, N, H, W, Cin, OH, OW, Cout);
+    if (a.npatch == 0) return YOLO_ERR_ARG;
+    const WgPlan p = make_plan(a, k);
+    int rc;
+    if (dtype == YOLO_BF16) rc = launch_ks<bf16_t>(a, p, k, stride, x, dy, part, st);
+    else if (dtype == YOLO_F16) rc = launch_ks<f16_t>(a, p, k, stride, x, dy, part, st);
+    else return YOLO_ERR_DTYPE;
+    if (rc) return rc;
+    const long total = (long)Cout * Cin * k * k;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (dw_dtype == YOLO_F32) hipLaunchKernelGGL((k_wgrad_reduce<float>), dim3(grid), dim3(256), 0, st, part, p.nslab, Cout, Cin, k * k, Kpad, (float*)dw_oihw);
+    else if (dw_dtype == YOLO_BF16) hipLaunchKernelGGL((k_wgrad_reduce<bf16_t>), dim3(grid), dim3(256), 0, st, part, p.nslab, Cout, Cin, k * k, Kpad, (bf16_t*)dw_oihw);
+    else if (dw_dtype == YOLO_F16) hipLaunchKernelGGL((k_wgrad_reduce<f16_t>), dim3(grid), dim3(256), 0, st, part, p.nslab, Cout, Cin, k * k, Kpad, (f16_t*)dw_oihw);
+    else return YOLO_ERR_DTYPE;
+    return YOLO_LAUNCH_CHECK();
 }

@@ -247,16 +247,15 @@ def conv_dgrad(dy, wb, cin, h, w, k, stride):
 
 
 def conv_wgrad(x, dy, k, stride, w_dtype):
+    """OIHW weight gradient in w_dtype.  The kernels write per-slab partial matrices into a scratch buffer and a
+    reduce pass sums them straight into the OIHW tensor (no memset, no atomics, no separate unpack)."""
     n, cin, h, w, ldx = geom(x)
     _, cout, oh, ow, ldy = geom(dy)
-    kpad = lib.query("yolo_conv_kpad", cout, cin, k, stride, 0, 0)
-    dwp = torch.empty(cout * kpad, dtype=torch.float32, device=x.device)
-    lib.call("yolo_conv2d_wgrad", _p(x), ldx, _p(dy), ldy, _p(dwp), n, h, w, cin, oh, ow, cout, k, stride, dt(x),
-             ALGO, _stream(x))
-    if k == 1 and kpad == cin and w_dtype == torch.float32:
-        return dwp.view(cout, cin, 1, 1)            # packed [Cout][Cin] IS the OIHW layout: no unpack pass
+    args = (n, h, w, cin, oh, ow, cout, k, stride, dt(x), ALGO)
+    ws = torch.empty(lib.query("yolo_conv2d_wgrad_ws_elems", _p(x), ldx, _p(dy), ldy, *args), dtype=torch.float32,
+                     device=x.device)
     dw = torch.empty((cout, cin, k, k), dtype=w_dtype, device=x.device)
-    lib.call("yolo_conv_unpack_wgrad", _p(dwp), cout, cin, k, _p(dw), dt(w_dtype), _stream(x))
+    lib.call("yolo_conv2d_wgrad", _p(x), ldx, _p(dy), ldy, _p(ws), _p(dw), dt(w_dtype), *args, _stream(x))
     return dw
 
 

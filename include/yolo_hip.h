@@ -57,7 +57,8 @@ long yolo_pack_jobs_finalize(void* jobs_host, int njobs);
 int yolo_pack_batched(const void* jobs_dev, int njobs, long nchunks, int out_dtype, hipStream_t st);
 int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
-int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dwp, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
+long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo);
+int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws, void* dw_oihw, int dw_dtype, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 /* stem (3 -> C, 3x3 stride 2: backbone.py:38): NCHW image unfolded to K = 27(+5) columns, then the 1x1 MFMA path */
 int yolo_stem_im2col(const void* img, int img_dtype, void* col, int col_dtype, int N, int H, int W, int OH, int OW, hipStream_t st);
 int yolo_stem_pack_weights(const void* w, int w_dtype, int Cout, void* out, int out_dtype, hipStream_t st);
