@@ -13,6 +13,8 @@
 // pixel, which is the slow axis of NHWC, so both tiles are transposed on their way into LDS
 // (pixel-major inner) and the K loop runs over 32-pixel steps of one slab; slabs are combined with
 // fp32 atomics into the packed gradient matrix.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "conv_geom.h"
 
@@ -45,6 +47,7 @@ constexpr int LDSROW = 32; // elements per LDS row: unpadded 64-byte rows whose 
 struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic indexing of kernargs)
     int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, Hg, Wg, ostep, ooff_h, ooff_w, sstride, ntaps, KT, Kpad;
     unsigned dh_pack, dw_pack;   // 2 bits per tap: value + 1
+    int tap_inner;               // MODE 2 K order: 1 = taps innermost, 0 = channel chunks innermost
     float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
 };
 
@@ -167,9 +170,15 @@ __global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restric
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsb, voffb[i], wcol * 2, 0);
                 rb[i] = make_uint4(v.x, v.y, v.z, v.w);
             }
-            ++tap;
-            wcol += g.Cs;
-            if (tap == g.ntaps) { tap = 0; cbase += BK; wcol += BK - g.ntaps * g.Cs; }
+            if (g.tap_inner) {
+                ++tap;
+                wcol += g.Cs;
+                if (tap == g.ntaps) { tap = 0; cbase += BK; wcol += BK - g.ntaps * g.Cs; }
+            } else {
+                cbase += BK;
+                wcol += BK;
+                if (cbase == g.Cs) { cbase = 0; ++tap; }
+            }
         } else {
             const bool tv = ltap < g.ntaps;
             const int dh = (int)((g.dh_pack >> (2 * ltap)) & 3u) - 1, dw = (int)((g.dw_pack >> (2 * ltap)) & 3u) - 1;
@@ -420,6 +429,7 @@ GeomDev to_dev(const ConvGeom& g) {
     d.sstride = g.sstride; d.ntaps = g.ntaps; d.Kpad = g.Kpad; d.KT = g.Kpad / BK;
     d.dh_pack = d.dw_pack = 0;
     d.stats = g.stats;
+    d.tap_inner = 0;
     for (int t = 0; t < g.ntaps; ++t) {
         d.dh_pack |= (unsigned)(g.dh[t] + 1) << (2 * t);
         d.dw_pack |= (unsigned)(g.dw[t] + 1) << (2 * t);
@@ -444,14 +454,21 @@ void launch_tile(const GeomDev& d, const void* src, const void* wm, const float*
 }
 
 template <typename T>
-void launch_conv_t(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+void launch_conv_t(const GeomDev& d_in, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                    hipStream_t st) {
     // widest channel tile that still yields >= 2 workgroups per CU; small maps with many channels (20x20, K in
     // the thousands) otherwise run ~100 workgroups through a 144-step K loop on a 256-CU chip
-    const long tm = ((long)d.N * d.Hg * d.Wg + BM - 1) / BM;
-    auto blocks = [&](int bn) { return tm * ((d.Cd + bn - 1) / bn); };
-    int bn = d.Cd > 64 ? 128 : (d.Cd > 32 ? 64 : 32);
+    const long tm = ((long)d_in.N * d_in.Hg * d_in.Wg + BM - 1) / BM;
+    auto blocks = [&](int bn) { return tm * ((d_in.Cd + bn - 1) / bn); };
+    int bn = d_in.Cd > 64 ? 128 : (d_in.Cd > 32 ? 64 : 32);
     while (bn > 32 && blocks(bn) < 512) bn >>= 1;
+    GeomDev d = d_in;
+    if (const char* e = getenv("YOLO_CONV_TUNE")) {          // "bn,tap_inner": tuning runs only
+        int v[2] = {0, -1};
+        sscanf(e, "%d,%d", &v[0], &v[1]);
+        if (v[0] == 32 || v[0] == 64 || v[0] == 128) bn = v[0];
+        if (v[1] >= 0) d.tap_inner = v[1];
+    }
     if (bn == 128) launch_tile<T, 2, 2, 4, 4>(d, src, wm, bias, dst, accumulate, st);        // 128 x 128
     else if (bn == 64) launch_tile<T, 2, 2, 4, 2>(d, src, wm, bias, dst, accumulate, st);    // 128 x 64
     else launch_tile<T, 4, 1, 2, 2>(d, src, wm, bias, dst, accumulate, st);                  // 128 x 32

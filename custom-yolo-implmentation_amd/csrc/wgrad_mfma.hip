@@ -199,22 +199,51 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
             }
 }
 
-// sum of the slabs' partial matrices -> OIHW gradient in the parameter's dtype (replaces memset + unpack)
-template <typename TO>
-__global__ void k_wgrad_reduce(const float* __restrict__ part, int nslab, int Cout, int Cin, int NT, int Kpad,
-                               TO* __restrict__ dw) {
+// sum of the slabs' partial matrices -> OIHW gradient in the parameter's dtype (replaces memset + unpack).
+// A workgroup covers 256/SL consecutive packed elements with SL lanes each striding over the slabs, so a
+// 128 x 128 matrix with 512 slabs is summed by 1024 workgroups with 32 loads per thread in flight-able batches
+// (one thread per element walking all slabs was a 20 us dependent chain per layer).
+template <typename TO, int SL>
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nslab, int Cout, int Cin, int NT,
+                                                      int Kpad, TO* __restrict__ dw) {
+    constexpr int EL = 256 / SL;
+    __shared__ float red[SL][EL + 1];
+    const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
     const long total = (long)Cout * Cin * NT;
     const long slab = (long)Cout * Kpad;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int K = Cin * NT;
-        const int co = (int)(e / K), k = (int)(e - (long)co * K);      // packed order: k = tap*Cin + ci
-        const int t = k / Cin, ci = k - t * Cin;
+    const long e = (long)blockIdx.x * EL + el;
+    const int K = Cin * NT;
+    int co = 0, k = 0;
+    float a = 0.f;
+    if (e < total) {
+        co = (int)(e / K);
+        k = (int)(e - (long)co * K);                          // packed order: k = tap*Cin + ci
         const float* p = part + (long)co * Kpad + k;
-        float a = 0.f;
-#pragma unroll 4
-        for (int s2 = 0; s2 < nslab; ++s2) a += p[s2 * slab];
+#pragma unroll 8
+        for (int s2 = sl; s2 < nslab; s2 += SL) a += p[s2 * slab];
+    }
+    if (SL > 1) {
+        red[sl][el] = a;
+        __syncthreads();
+        if (sl != 0) return;
+#pragma unroll
+        for (int s2 = 1; s2 < SL; ++s2) a += red[s2][el];
+    }
+    if (e < total) {
+        const int t = k / Cin, ci = k - t * Cin;
         dw[((long)co * Cin + ci) * NT + t] = (TO)a;
     }
+}
+
+template <typename TO>
+void launch_reduce(const float* part, int nslab, int Cout, int Cin, int NT, int Kpad, void* dw, hipStream_t st) {
+    const long total = (long)Cout * Cin * NT;
+    if (nslab >= 32)
+        hipLaunchKernelGGL((k_wgrad_reduce<TO, 16>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, part, nslab, Cout, Cin, NT, Kpad, (TO*)dw);
+    else if (nslab >= 4)
+        hipLaunchKernelGGL((k_wgrad_reduce<TO, 4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, nslab, Cout, Cin, NT, Kpad, (TO*)dw);
+    else
+        hipLaunchKernelGGL((k_wgrad_reduce<TO, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, nslab, Cout, Cin, NT, Kpad, (TO*)dw);
 }
 
 struct WgPlan { int to, ti, cot, cit, nslab; long per_slab; };
@@ -319,11 +348,9 @@ int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* p
     else if (dtype == YOLO_F16) rc = launch_ks<f16_t>(a, p, k, stride, x, dy, part, st);
     else return YOLO_ERR_DTYPE;
     if (rc) return rc;
-    const long total = (long)Cout * Cin * k * k;
-    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    if (dw_dtype == YOLO_F32) hipLaunchKernelGGL((k_wgrad_reduce<float>), dim3(grid), dim3(256), 0, st, part, p.nslab, Cout, Cin, k * k, Kpad, (float*)dw_oihw);
-    else if (dw_dtype == YOLO_BF16) hipLaunchKernelGGL((k_wgrad_reduce<bf16_t>), dim3(grid), dim3(256), 0, st, part, p.nslab, Cout, Cin, k * k, Kpad, (bf16_t*)dw_oihw);
-    else if (dw_dtype == YOLO_F16) hipLaunchKernelGGL((k_wgrad_reduce<f16_t>), dim3(grid), dim3(256), 0, st, part, p.nslab, Cout, Cin, k * k, Kpad, (f16_t*)dw_oihw);
+    if (dw_dtype == YOLO_F32) launch_reduce<float>(part, p.nslab, Cout, Cin, k * k, Kpad, dw_oihw, st);
+    else if (dw_dtype == YOLO_BF16) launch_reduce<bf16_t>(part, p.nslab, Cout, Cin, k * k, Kpad, dw_oihw, st);
+    else if (dw_dtype == YOLO_F16) launch_reduce<f16_t>(part, p.nslab, Cout, Cin, k * k, Kpad, dw_oihw, st);
     else return YOLO_ERR_DTYPE;
     return YOLO_LAUNCH_CHECK();
 }
