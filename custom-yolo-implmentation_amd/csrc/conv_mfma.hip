@@ -456,12 +456,16 @@ void launch_tile(const GeomDev& d, const void* src, const void* wm, const float*
 template <typename T>
 void launch_conv_t(const GeomDev& d_in, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                    hipStream_t st) {
-    // widest channel tile that still yields >= 2 workgroups per CU; small maps with many channels (20x20, K in
-    // the thousands) otherwise run ~100 workgroups through a 144-step K loop on a 256-CU chip
+    // Tile width (tools/conv_tune.py on MI355X): the widest channel tile that still yields one workgroup per CU --
+    // small maps with many channels (20x20, K in the thousands) otherwise run ~100 workgroups through a 144-step
+    // K loop on a 256-CU chip; narrower tiles than that only add LDS reads per MFMA.  One-tap convs whose source
+    // stays in the 256 MB Infinity Cache prefer 64-wide tiles (re-reading the source per channel tile is cheap there).
     const long tm = ((long)d_in.N * d_in.Hg * d_in.Wg + BM - 1) / BM;
     auto blocks = [&](int bn) { return tm * ((d_in.Cd + bn - 1) / bn); };
     int bn = d_in.Cd > 64 ? 128 : (d_in.Cd > 32 ? 64 : 32);
-    while (bn > 32 && blocks(bn) < 512) bn >>= 1;
+    const long src_bytes = (long)d_in.N * d_in.Hs * d_in.Ws * d_in.lds * 2;
+    if (bn == 128 && d_in.ntaps == 1 && src_bytes <= (128L << 20)) bn = 64;
+    while (bn > 32 && blocks(bn) < 256) bn >>= 1;
     GeomDev d = d_in;
     if (const char* e = getenv("YOLO_CONV_TUNE")) {          // "bn,tap_inner": tuning runs only
         int v[2] = {0, -1};
