@@ -79,7 +79,7 @@ __device__ __forceinline__ float row16_sum(float x) {
 //   or a row past the end is a voffset beyond the descriptor's range, which the hardware reads as zero -- the
 //   gather costs 3 vector instructions per row and step.  All sizes are below 2^30 elements (host check).
 template <typename T, int WGM, int WGN, int WM, int WN, bool ACC, int MODE>
-__global__ __launch_bounds__(256) void k_conv_mfma(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conv_mfma(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
                                                    const float* __restrict__ bias, T* __restrict__ dst, int ntile_n) {
     static_assert(WGM * WGN == 4 && WGM * WM * 16 == BM, "tile shape");
     constexpr int BN = WGN * WN * 16;
