@@ -264,7 +264,7 @@ WgPlan make_plan(const WgArgs& a, int k) {
         p.to = a.Cout > 32 ? 2 : 1;
         p.ti = a.Cin > 64 ? 2 : 1;
     }
-    long want_blocks = (k == 1 && p.to * p.ti == 1) ? 1024 : 512;
+    long want_blocks = (k == 1 && p.to * p.ti == 1) ? 1024 : (k == 3 ? 256 : 512);
     long min_per = 2;
     if (const char* e = getenv("YOLO_WG_TUNE")) {            // "to,ti,blocks,min_per": tuning runs only
         int v[4] = {0, 0, 0, 0};
