@@ -1,0 +1,76 @@
+// Device-side pieces shared by the conv kernels (conv_mfma.hip, conv_halo.hip): MFMA wrappers, the packed
+// geometry passed by value, the XCD-aware tile order and the 16-lane row reduction.
+#pragma once
+#include "common.h"
+#include "conv_geom.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <typename T> struct mfma_ops;
+template <> struct mfma_ops<bf16_t> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct mfma_ops<f16_t> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+constexpr int BM = 128;    // destination pixels per workgroup
+constexpr int BK = 32;     // K elements per step (one MFMA K)
+constexpr int LDSROW = 32; // elements per LDS row: unpadded 64-byte rows whose four 16-byte chunks are XOR-swizzled
+                           // by (-(row >> 2)) & 3 -- conflict-free for ds_read_b128 fragment reads (16 rows x 1 chunk
+                           // per lane group) and for the ds_write_b128 staging (2 rows x 4 chunks per 8 lanes)
+
+struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic indexing of kernargs)
+    int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, Hg, Wg, ostep, ooff_h, ooff_w, sstride, ntaps, KT, Kpad;
+    unsigned dh_pack, dw_pack;   // 2 bits per tap: value + 1
+    int tap_inner;               // MODE 2 K order: 1 = taps innermost, 0 = channel chunks innermost
+    float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// bijective XCD-aware remap (guide T1): blocks that share an XCD get a contiguous range of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// x + (x rotated by N lanes inside its row of 16): one VALU op (v_add_f32 with a DPP operand)
+template <int N> __device__ __forceinline__ float row_ror_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x = row_ror_add<8>(x);
+    x = row_ror_add<4>(x);
+    x = row_ror_add<2>(x);
+    return row_ror_add<1>(x);
+}
+
+
+inline GeomDev to_dev(const ConvGeom& g) {
+    GeomDev d;
+    d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd;
+    d.ldd = g.ldd; d.Hg = g.Hg; d.Wg = g.Wg; d.ostep = g.ostep; d.ooff_h = g.ooff_h; d.ooff_w = g.ooff_w;
+    d.sstride = g.sstride; d.ntaps = g.ntaps; d.Kpad = g.Kpad; d.KT = g.Kpad / BK;
+    d.dh_pack = d.dw_pack = 0;
+    d.stats = g.stats;
+    d.tap_inner = 0;
+    for (int t = 0; t < g.ntaps; ++t) {
+        d.dh_pack |= (unsigned)(g.dh[t] + 1) << (2 * t);
+        d.dw_pack |= (unsigned)(g.dw[t] + 1) << (2 * t);
+    }
+    return d;
+}
+
+
+}  // namespace

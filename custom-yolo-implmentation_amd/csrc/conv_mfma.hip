@@ -17,58 +17,13 @@
 #include <cstdlib>
 #include "common.h"
 #include "conv_geom.h"
+#include "conv_dev.h"
+
+int halo_conv_eligible(const ConvGeom& g);
+int halo_conv_launch(const ConvGeom& g, int variant, const void* src, const void* wm, const float* bias, void* dst,
+                     int accumulate, int dtype, hipStream_t st);
 
 namespace {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
-template <typename T> struct mfma_ops;
-template <> struct mfma_ops<bf16_t> {
-    typedef bf16x8 frag;
-    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct mfma_ops<f16_t> {
-    typedef f16x8 frag;
-    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-    }
-};
-
-constexpr int BM = 128;    // destination pixels per workgroup
-constexpr int BK = 32;     // K elements per step (one MFMA K)
-constexpr int LDSROW = 32; // elements per LDS row: unpadded 64-byte rows whose four 16-byte chunks are XOR-swizzled
-                           // by (-(row >> 2)) & 3 -- conflict-free for ds_read_b128 fragment reads (16 rows x 1 chunk
-                           // per lane group) and for the ds_write_b128 staging (2 rows x 4 chunks per 8 lanes)
-
-struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic indexing of kernargs)
-    int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, Hg, Wg, ostep, ooff_h, ooff_w, sstride, ntaps, KT, Kpad;
-    unsigned dh_pack, dw_pack;   // 2 bits per tap: value + 1
-    int tap_inner;               // MODE 2 K order: 1 = taps innermost, 0 = channel chunks innermost
-    float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
-};
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// bijective XCD-aware remap (guide T1): blocks that share an XCD get a contiguous range of tiles
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-
-// x + (x rotated by N lanes inside its row of 16): one VALU op (v_add_f32 with a DPP operand)
-template <int N> __device__ __forceinline__ float row_ror_add(float x) {
-    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float x) {
-    x = row_ror_add<8>(x);
-    x = row_ror_add<4>(x);
-    x = row_ror_add<2>(x);
-    return row_ror_add<1>(x);
-}
 
 // MODE 0: K walked tap-major (k = tap*Cs + ch), any Cs % 8 == 0; each lane tracks its own (tap, ch).
 // MODE 1: the same with Cs < 32 (a step can cross several taps).
@@ -422,21 +377,6 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const T* __restrict__ x, int
         }
 }
 
-GeomDev to_dev(const ConvGeom& g) {
-    GeomDev d;
-    d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd;
-    d.ldd = g.ldd; d.Hg = g.Hg; d.Wg = g.Wg; d.ostep = g.ostep; d.ooff_h = g.ooff_h; d.ooff_w = g.ooff_w;
-    d.sstride = g.sstride; d.ntaps = g.ntaps; d.Kpad = g.Kpad; d.KT = g.Kpad / BK;
-    d.dh_pack = d.dw_pack = 0;
-    d.stats = g.stats;
-    d.tap_inner = 0;
-    for (int t = 0; t < g.ntaps; ++t) {
-        d.dh_pack |= (unsigned)(g.dh[t] + 1) << (2 * t);
-        d.dw_pack |= (unsigned)(g.dw[t] + 1) << (2 * t);
-    }
-    return d;
-}
-
 template <typename T, int WGM, int WGN, int WM, int WN>
 void launch_tile(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                  hipStream_t st) {
@@ -494,10 +434,31 @@ int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void
     return 1;
 }
 
+// 3x3 stride-1 layers take the halo kernel (conv_halo.hip) when the map is large enough for its 8x16 / 16x16 pixel
+// tiles to fill the chip; variant choice from tools/conv_tune.py.  YOLO_CONV_TUNE's third field overrides it
+// (0 = gather kernel, 1..4 = halo variant) for tuning runs.
+static int halo_variant(const ConvGeom& g) {
+    int v = -1;
+    if (const char* e = getenv("YOLO_CONV_TUNE")) {
+        int a = 0, b = 0, c = -1;
+        sscanf(e, "%d,%d,%d", &a, &b, &c);
+        v = c;
+    }
+    if (!halo_conv_eligible(g)) return 0;
+    if (v >= 0) return v > 4 ? 0 : v;
+    // measured in the training step (preset s, 32 images): the halo kernel wins on maps of 80x80 and more
+    // (16x16-pixel tiles: 63 vs 81 us for 128->64 @80x80) and on 40x40 with exactly two 64-channel wave columns;
+    // on smaller maps / other widths its tiles are too few or half empty and the gather kernel is level or better
+    if ((long)g.Hg * g.Wg >= 80 * 80) return g.Cd >= 128 ? 2 : 3;
+    if (g.Hg >= 40 && g.Wg >= 40 && g.Cd == 128) return 1;
+    return 0;
+}
+
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                      int dtype, hipStream_t st) {
+    if ((long)g.N * g.Hg * g.Wg == 0) return YOLO_OK;
+    if (const int hv = halo_variant(g)) return halo_conv_launch(g, hv, src, wm, bias, dst, accumulate, dtype, st);
     GeomDev d = to_dev(g);
-    if ((long)d.N * d.Hg * d.Wg == 0) return YOLO_OK;
     if (dtype == YOLO_BF16) launch_conv_t<bf16_t>(d, src, wm, bias, dst, accumulate, st);
     else launch_conv_t<f16_t>(d, src, wm, bias, dst, accumulate, st);
     return YOLO_LAUNCH_CHECK();

@@ -38,9 +38,13 @@ for (n, cin, h, w, cout, k, s) in shapes:
         res = []
         for bn in (128, 64, 32):
             for ti in ((0, 1) if k == 3 else (0,)):
-                os.environ["YOLO_CONV_TUNE"] = f"{bn},{ti}"
+                os.environ["YOLO_CONV_TUNE"] = f"{bn},{ti},0"
                 res.append((timeit(fn, 0.08), bn, ti))
+        if k == 3 and s == 1:
+            for hv in (1, 2, 3, 4):
+                os.environ["YOLO_CONV_TUNE"] = f"0,0,{hv}"
+                res.append((timeit(fn, 0.08), "halo", hv))
         res.sort()
         mb = (x.numel() + dy.numel()) * 2 / 1e6
         print(f"{name:5s} ({n},{cin},{h},{w})->{cout} k{k}s{s} {mb:5.0f} MB ideal {mb/4.5:6.1f} us | default {base:7.1f} | " +
-              "  ".join(f"{u:6.1f}@bn{b}/ti{t}" for u, b, t in res[:4]), flush=True)
+              "  ".join(f"{u:6.1f}@bn{b}/ti{t}" for u, b, t in res[:5]), flush=True)
