@@ -4,8 +4,11 @@ One training step of the small model is ~1000 short kernels; issued eagerly from
 between them.  `TrainStepRunner` captures forward + loss + backward (+ the optimizer step when it is
 capturable) into one hipGraph on static buffers and replays it; data-parallel gradient averaging
 (DDP semantics: mean over ranks, src/training/utils_train.py:190) runs between the backward graph and
-the optimizer as ONE flat RCCL all-reduce per dtype bucket -- xGMI is point-to-point, a few large
-messages beat DDP's default 25 MB bucket train for a 38 MB model.
+the optimizer as ONE flat RCCL all-reduce -- xGMI is point-to-point, one large message beats DDP's default
+25 MB bucket train for a 38 MB model.  With a process group the step is TWO graphs around that collective:
+graph 1 = forward + loss + backward + "pack all gradients into the flat communication buffer" (one multi-tensor
+copy, bf16-compressed if asked), then `all_reduce(AVG)` on the flat buffer, then graph 2 = "unpack into the
+gradients" + the (capturable) optimizer step -- a dozen launches per step from the host instead of ~300.
 """
 import torch
 import torch.distributed as dist
@@ -13,16 +16,21 @@ from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 
 class TrainStepRunner:
-    def __init__(self, model, criterion, optimizer, precision="bfloat16", use_graph=True, grad_comm_dtype=None):
+    def __init__(self, model, criterion, optimizer, precision="bfloat16", use_graph=True, grad_comm_dtype=None,
+                 force_comm=False):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.amp_dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(precision)
         self.use_graph = use_graph
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.comm_dtype = grad_comm_dtype
+        # the collective path; force_comm runs it on a one-rank group too (single-GPU test of the two-graph step)
+        self.comm = self.world > 1 or (force_comm and dist.is_available() and dist.is_initialized())
         self.params = [p for p in model.parameters() if p.requires_grad]
         if hasattr(model, "_prepack"):          # plain local parameters here: pack all conv weights in one launch
             model.prepack = True
         self.graph = None
+        self.graph2 = None                      # world > 1: unpack + optimizer, replayed after the all-reduce
+        self.flat = None
         self.opt_in_graph = False
         self.static = None
         self.loss = None
@@ -38,7 +46,7 @@ class TrainStepRunner:
         return loss, ld
 
     def _allreduce(self):
-        if self.world == 1:
+        if not self.comm:
             return
         grads = [p.grad for p in self.params if p.grad is not None]
         flat = _flatten_dense_tensors(grads)
@@ -72,7 +80,8 @@ class TrainStepRunner:
                 self._eager_step(images, packed)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        want_opt = self.world == 1 and all(g.get("capturable", False) for g in self.optimizer.param_groups)
+        capturable = all(g.get("capturable", False) for g in self.optimizer.param_groups)
+        want_opt = not self.comm and capturable
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -80,8 +89,39 @@ class TrainStepRunner:
             self.scalars = ld._scalars
             if want_opt:
                 self.optimizer.step()
+            elif self.comm:
+                self._pack_grads()
         self.graph, self.opt_in_graph = g, want_opt
+        if self.comm and capturable:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g.pool()):
+                self._unpack_grads()
+                self.optimizer.step()
+            self.graph2 = g2
         return self
+
+    # ---- flat communication buffer (world > 1, graph mode): gradients are static tensors after capture
+    def _pack_grads(self):
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if self.flat is None:
+            dt = self.comm_dtype or grads[0].dtype
+            self.flat = torch.empty(sum(g.numel() for g in grads), dtype=dt, device=grads[0].device)
+            self._views, off = [], 0
+            for g in grads:
+                self._views.append(self.flat[off:off + g.numel()].view(g.shape))
+                off += g.numel()
+        self._grads = grads
+        torch._foreach_copy_(self._views, grads)             # one multi-tensor launch per ~100 tensors, casts included
+
+    def _unpack_grads(self):
+        torch._foreach_copy_(self._grads, self._views)
+
+    def _reduce_flat(self):
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+        else:                                                 # gloo has no AVG
+            dist.all_reduce(self.flat)
+            self.flat.div_(self.world)
 
     def step(self):
         """One optimizer step on the static batch; returns the (device) loss tensor of that step."""
@@ -91,7 +131,13 @@ class TrainStepRunner:
             self.scalars = ld._scalars
             return loss
         self.graph.replay()
-        if not self.opt_in_graph:
-            self._allreduce()
-            self.optimizer.step()
+        if self.opt_in_graph:
+            return self.loss
+        if self.comm:
+            self._reduce_flat()
+            if self.graph2 is not None:
+                self.graph2.replay()
+                return self.loss
+            self._unpack_grads()
+        self.optimizer.step()
         return self.loss

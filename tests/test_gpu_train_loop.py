@@ -46,3 +46,43 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, tmp_path):
     assert ck["epoch"] == 1 and "model_state" in ck and "optimizer_state" in ck
     keys = set(ck["model_state"].keys())
     assert any(k.endswith("net.p1.0.conv.weight") for k in keys) and any(k.endswith("head.dfl.conv.weight") for k in keys)
+
+
+def test_two_graph_data_parallel_step_equals_single_graph_step(pg):
+    """The N > 1 step of TrainStepRunner (graph 1: fwd+bwd+pack gradients, RCCL all-reduce, graph 2: unpack + AdamW)
+    on a one-rank RCCL group must move the weights exactly like the single-graph step; with bf16-compressed
+    gradients it must stay within bf16 rounding of it."""
+    from src.model.losses import PackedTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.graph_step import TrainStepRunner
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(2, 3, 160, 160, generator=g).cuda()
+    gts = [torch.cat([torch.rand(3, 2, generator=g) * 160, torch.rand(3, 2, generator=g) * 60 + 8,
+                      torch.randint(0, 80, (3, 1), generator=g).float()], 1).cuda() for _ in range(2)]
+
+    def run(force, comm_dtype):
+        torch.manual_seed(0)
+        model = Model(**NANO, num_classes=80).cuda().train()
+        # lr 0: the weights stay put, so the gradients of the last step are comparable across runs (an Adam update is
+        # sign-like for near-zero gradients and would amplify the last-bit noise of the atomically summed statistics)
+        opt = torch.optim.AdamW(model.parameters(), lr=0.0, weight_decay=0.0, capturable=True, fused=True)
+        # fp32 compute: the only run-to-run noise left is the last bits of the atomically summed batch statistics
+        r = TrainStepRunner(model, YoloDFLQFLoss(num_classes=80), opt, "float32", use_graph=True,
+                            grad_comm_dtype=comm_dtype, force_comm=force)
+        r.capture(img, PackedTargets(gts, img.device), warmup=1)
+        for _ in range(2):
+            r.step()
+        torch.cuda.synchronize()
+        assert (r.graph2 is not None) == force
+        st = opt.state[next(iter(model.parameters()))]
+        assert int(st["step"]) >= 2                                     # the optimizer really stepped (in graph 2)
+        return [p.grad.detach().float().clone() for p in model.parameters() if p.grad is not None]
+
+    base, same, comp = run(False, None), run(True, None), run(True, torch.bfloat16)
+    gmax = max(float(a.abs().max()) for a in base)
+    for a, b, c in zip(base, same, comp):
+        scale = a.abs().max().clamp_min(1e-3 * gmax)       # some gradients are mathematically zero (noise only)
+        assert torch.isfinite(b).all() and torch.isfinite(c).all()
+        assert (a - b).abs().max() / scale < 1e-3, "pack / all-reduce / unpack changed the gradients"
+        assert (a - c).abs().max() / scale < 1e-2, "bf16-compressed exchange outside bf16 rounding"
+    assert any(not torch.equal(a, c) for a, c in zip(base, comp))
