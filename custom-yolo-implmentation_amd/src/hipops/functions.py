@@ -60,7 +60,7 @@ class ConvBnAct(torch.autograd.Function):
     separate pass over y); the backward uses the deterministic two-level reduction."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps):
+    def forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps, out=None):
         T = compute_dtype(x, weight)
         cout = weight.shape[0]
         acc_f = None
@@ -96,11 +96,11 @@ class ConvBnAct(torch.autograd.Function):
         else:
             mean = invstd = None
             scale, shift = ops.bn_eval_coeffs(g32, b32, _f32(rm), _f32(rv), eps)
-        out = ops.bn_act_fwd(y, scale, shift, act, res)
+        out = ops.bn_act_fwd(y, scale, shift, act, res, out)
         saved = (scale, shift, mean, invstd, g32)
         ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype, stem)
         ctx.save_for_backward(x, weight, y, *saved)
-        return out
+        return _fresh(out)
 
     @staticmethod
     def backward(ctx, dout):
@@ -133,7 +133,7 @@ class ConvBnAct(torch.autograd.Function):
         else:
             dgamma = dbeta = None
         dres = dout if (has_res and ctx.needs_input_grad[4]) else None
-        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 class ConvBias(torch.autograd.Function):
@@ -166,7 +166,7 @@ class ConvBias(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-def fused_conv_act(x, weight, bias, k, stride, depthwise, act, res=None):
+def fused_conv_act(x, weight, bias, k, stride, depthwise, act, res=None, out=None):
     """Conv with BN folded in (Model.fuse(), src/model/model_blocks.py:36-37): act(conv(x) + b) (+ res).
     Inference-only like the reference's fused conv (requires_grad False); no autograd node."""
     with torch.no_grad():
@@ -175,13 +175,13 @@ def fused_conv_act(x, weight, bias, k, stride, depthwise, act, res=None):
         cout = weight.shape[0]
         b32 = _f32(bias)
         if not depthwise and act == ACT_IDENTITY and res is None:
-            return ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), b32, cout, k, stride)
+            return ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), b32, cout, k, stride, out=out)
         if depthwise:
             y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9))
         else:
             y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride)
         one = ops.fill_(torch.empty(cout, dtype=torch.float32, device=x.device), 1.0)
-        return ops.bn_act_fwd(y, one, b32, act, None if res is None else _as_nhwc(res, T))
+        return ops.bn_act_fwd(y, one, b32, act, None if res is None else _as_nhwc(res, T), out)
 
 
 class Cat(torch.autograd.Function):
@@ -205,6 +205,50 @@ class Cat(torch.autograd.Function):
     def backward(ctx, dout):
         dout = _as_nhwc(dout, dout.dtype)
         grads, off = [], 0
+        for c in ctx.cs:
+            grads.append(dout[:, off:off + c])
+            off += c
+        return tuple(grads)
+
+
+def _fresh(t):
+    """A Function output must not BE one of its inputs: hand back a new tensor object on the same memory
+    (the caller's `out=` view) so autograd attaches the node to it without view / in-place bookkeeping."""
+    return t.detach() if t is not None else t
+
+
+def cat_buffer(like, weight, channels):
+    """Concat buffer for producers that write their channel slice in place (see CatInto): NHWC, the compute dtype
+    the producers will use for `like` (autocast-aware), `like`'s batch and map size."""
+    n, _, h, w = like.shape
+    return ops.new_nhwc(n, channels, h, w, compute_dtype(like, weight), like.device)
+
+
+class CatInto(torch.autograd.Function):
+    """torch.cat(dim=1) without the copies: `buf` is the concat buffer, xs[i] its consecutive channel slices.  A
+    producer that was handed its slice as `out=` has already written it (same memory: nothing to do); any other
+    input (a tensor produced elsewhere, e.g. a backbone feature entering the neck) is copied in.  Backward hands
+    out slices of the incoming gradient, like Cat."""
+
+    @staticmethod
+    def forward(ctx, buf, *xs):
+        off, cs = 0, []
+        for x in xs:
+            c = x.shape[1]
+            dst = buf[:, off:off + c]
+            if x.data_ptr() != dst.data_ptr() or x.stride() != dst.stride():
+                ops.copy_channels(_as_nhwc(x, buf.dtype), dst)
+            cs.append(c)
+            off += c
+        if off != buf.shape[1]:
+            raise RuntimeError("CatInto: slices do not cover the buffer")
+        ctx.cs = cs
+        return _fresh(buf)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _as_nhwc(dout, dout.dtype)
+        grads, off = [None], 0
         for c in ctx.cs:
             grads.append(dout[:, off:off + c])
             off += c
@@ -239,27 +283,27 @@ class MaxPool5(torch.autograd.Function):
     """nn.MaxPool2d(5, 1, 2) (src/model/model_blocks.py:150)."""
 
     @staticmethod
-    def forward(ctx, x):
-        out, idx = ops.maxpool5_fwd(_as_nhwc(x, x.dtype))
+    def forward(ctx, x, out=None):
+        out, idx = ops.maxpool5_fwd(_as_nhwc(x, x.dtype), out)
         ctx.save_for_backward(idx)
-        return out
+        return _fresh(out)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return ops.maxpool5_bwd(_as_nhwc(dout, dout.dtype), idx)
+        return ops.maxpool5_bwd(_as_nhwc(dout, dout.dtype), idx), None
 
 
 class Upsample2x(torch.autograd.Function):
     """nn.Upsample(scale_factor=2), nearest (src/model/neck.py:31)."""
 
     @staticmethod
-    def forward(ctx, x):
-        return ops.upsample2x_fwd(_as_nhwc(x, x.dtype))
+    def forward(ctx, x, out=None):
+        return _fresh(ops.upsample2x_fwd(_as_nhwc(x, x.dtype), out))
 
     @staticmethod
     def backward(ctx, dout):
-        return ops.upsample2x_bwd(_as_nhwc(dout, dout.dtype))
+        return ops.upsample2x_bwd(_as_nhwc(dout, dout.dtype)), None
 
 
 class AttentionCore(torch.autograd.Function):

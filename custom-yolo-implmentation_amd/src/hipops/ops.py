@@ -37,6 +37,16 @@ def new_nhwc(n, c, h, w, dtype, device):
     return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
+def _dest(out, n, c, h, w, dtype, device):
+    """Destination of a producer: a fresh NHWC tensor, or the caller's view (typically a channel slice of a concat
+    buffer, so the consumer's torch.cat costs no copy -- every kernel takes a row stride `ld`)."""
+    if out is None:
+        return new_nhwc(n, c, h, w, dtype, device)
+    if tuple(out.shape) != (n, c, h, w) or out.dtype != dtype:
+        raise RuntimeError(f"out= has shape {tuple(out.shape)} / {out.dtype}, producer writes {(n, c, h, w)} / {dtype}")
+    return out
+
+
 def geom(x):
     """(N, C, H, W, ld) of an NHWC-in-memory tensor; raises if the memory is not pixel-dense NHWC."""
     n, c, h, w = x.shape
@@ -178,12 +188,12 @@ def conv_out_hw(h, w, k, stride):
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
-def conv_fwd(x, wp, bias, cout, k, stride, stats_acc=None):
+def conv_fwd(x, wp, bias, cout, k, stride, stats_acc=None, out=None):
     """y = conv(x); with stats_acc (fp32 [8][2][cout], zeroed) also accumulates sum(y), sum(y^2) per channel."""
     n, cin, h, w, ldx = geom(x)
     oh, ow = conv_out_hw(h, w, k, stride)
-    y = new_nhwc(n, cout, oh, ow, x.dtype, x.device)
-    lib.call("yolo_conv2d_fwd", _p(x), ldx, _p(wp), _p(bias), _p(y), cout, _p(stats_acc), n, h, w, cin, oh, ow, cout, k,
+    y = _dest(out, n, cout, oh, ow, x.dtype, x.device)
+    lib.call("yolo_conv2d_fwd", _p(x), ldx, _p(wp), _p(bias), _p(y), geom(y)[4], _p(stats_acc), n, h, w, cin, oh, ow, cout, k,
              stride, dt(x), ALGO, _stream(x))
     return y
 
@@ -337,11 +347,11 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return coef[:c], coef[c:]
 
 
-def bn_act_fwd(y, scale, shift, act, res=None):
+def bn_act_fwd(y, scale, shift, act, res=None, out=None):
     n, c, h, w, ld = geom(y)
-    out = new_nhwc(n, c, h, w, y.dtype, y.device)
+    out = _dest(out, n, c, h, w, y.dtype, y.device)
     ldr = geom(res)[4] if res is not None else 0
-    lib.call("yolo_bn_act_fwd", _p(y), ld, _p(scale), _p(shift), _p(res), ldr, _p(out), c, n * h * w, c, int(act),
+    lib.call("yolo_bn_act_fwd", _p(y), ld, _p(scale), _p(shift), _p(res), ldr, _p(out), geom(out)[4], n * h * w, c, int(act),
              dt(y), _stream(y))
     return out
 
@@ -389,11 +399,11 @@ def channel_sum(x):
 
 
 # ------------------------------------------------------------------------------------------------ pool / upsample
-def maxpool5_fwd(x):
+def maxpool5_fwd(x, out=None):
     n, c, h, w, ld = geom(x)
-    out = new_nhwc(n, c, h, w, x.dtype, x.device)
+    out = _dest(out, n, c, h, w, x.dtype, x.device)
     idx = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
-    lib.call("yolo_maxpool5_fwd", _p(x), ld, _p(out), c, _p(idx), n, h, w, c, dt(x), _stream(x))
+    lib.call("yolo_maxpool5_fwd", _p(x), ld, _p(out), geom(out)[4], _p(idx), n, h, w, c, dt(x), _stream(x))
     return out, idx
 
 
@@ -404,10 +414,10 @@ def maxpool5_bwd(dout, idx):
     return dx
 
 
-def upsample2x_fwd(x):
+def upsample2x_fwd(x, out=None):
     n, c, h, w, ld = geom(x)
-    out = new_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
-    lib.call("yolo_upsample2x_fwd", _p(x), ld, _p(out), c, n, h, w, c, dt(x), _stream(x))
+    out = _dest(out, n, c, 2 * h, 2 * w, x.dtype, x.device)
+    lib.call("yolo_upsample2x_fwd", _p(x), ld, _p(out), geom(out)[4], n, h, w, c, dt(x), _stream(x))
     return out
 
 

@@ -37,15 +37,16 @@ class Conv(nn.Module):
         self._k, self._s, self._dw, self._act = k, s, g != 1, _act_code(activation)
         self._count_batches = True      # a parent Model bumps all counters in one multi-tensor op instead
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, out=None):
+        """`out`: optional destination view (a channel slice of the consumer's concat buffer, F_.cat_buffer)."""
         n = self.norm
         if self.training and self._count_batches:
             n.num_batches_tracked.add_(1)
         return F_.ConvBnAct.apply(x, self.conv.weight, n.weight, n.bias, residual, (n.running_mean, n.running_var),
-                                  self._k, self._s, self._dw, self._act, self.training, n.momentum, n.eps)
+                                  self._k, self._s, self._dw, self._act, self.training, n.momentum, n.eps, out)
 
-    def fuse_forward(self, x, residual=None):
-        return F_.fused_conv_act(x, self.conv.weight, self.conv.bias, self._k, self._s, self._dw, self._act, residual)
+    def fuse_forward(self, x, residual=None, out=None):
+        return F_.fused_conv_act(x, self.conv.weight, self.conv.bias, self._k, self._s, self._dw, self._act, residual, out)
 
 
 class Residual(nn.Module):
@@ -57,8 +58,8 @@ class Residual(nn.Module):
         self.conv1 = Conv(ch, mid, nn.SiLU(), k=3, p=1)
         self.conv2 = Conv(mid, ch, nn.SiLU(), k=3, p=1)
 
-    def forward(self, x):
-        return self.conv2(self.conv1(x), x)
+    def forward(self, x, out=None):
+        return self.conv2(self.conv1(x), x, out=out)
 
 
 class C3K(nn.Module):
@@ -72,8 +73,13 @@ class C3K(nn.Module):
         self.conv3 = Conv(2 * half, out_ch, nn.SiLU())
         self.res_m = nn.Sequential(Residual(half, e=1.0), Residual(half, e=1.0))
 
-    def forward(self, x):
-        return self.conv3(F_.Cat.apply(self.res_m(self.conv1(x)), self.conv2(x)))
+    def forward(self, x, out=None):
+        # both branches write their half of the concat buffer directly (no torch.cat copy)
+        half = self.conv1.conv.out_channels
+        buf = F_.cat_buffer(x, self.conv1.conv.weight, 2 * half)
+        a = self.res_m[1](self.res_m[0](self.conv1(x)), out=buf[:, :half])
+        b = self.conv2(x, out=buf[:, half:])
+        return self.conv3(F_.CatInto.apply(buf, a, b), out=out)
 
 
 class C3K2(nn.Module):
@@ -88,10 +94,13 @@ class C3K2(nn.Module):
         self.res_m = nn.ModuleList((C3K(h, h) if csp else Residual(h)) for _ in range(n))
 
     def forward(self, x):
-        parts = list(F_.Chunk2.apply(self.conv1(x)))
-        for m in self.res_m:
-            parts.append(m(parts[-1]))
-        return self.conv2(F_.Cat.apply(*parts))
+        # conv1 and every chained block write straight into the concat buffer conv2 reads
+        h = self.conv1.conv.out_channels // 2
+        buf = F_.cat_buffer(x, self.conv1.conv.weight, (2 + len(self.res_m)) * h)
+        parts = list(F_.Chunk2.apply(self.conv1(x, out=buf[:, :2 * h])))     # two views of the buffer's head
+        for i, m in enumerate(self.res_m):
+            parts.append(m(parts[-1], out=buf[:, (2 + i) * h:(3 + i) * h]))
+        return self.conv2(F_.CatInto.apply(buf, *parts))
 
 
 class SPPF(nn.Module):
@@ -106,10 +115,13 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)   # kept for module-tree parity
 
     def forward(self, x):
-        x = self.cv1(x)
-        y1 = F_.MaxPool5.apply(x)
-        y2 = F_.MaxPool5.apply(y1)
-        return self.cv2(F_.Cat.apply(x, y1, y2, F_.MaxPool5.apply(y2)))
+        c = self.cv1.conv.out_channels
+        buf = F_.cat_buffer(x, self.cv1.conv.weight, 4 * c)
+        x = self.cv1(x, out=buf[:, :c])
+        y1 = F_.MaxPool5.apply(x, buf[:, c:2 * c])
+        y2 = F_.MaxPool5.apply(y1, buf[:, 2 * c:3 * c])
+        y3 = F_.MaxPool5.apply(y2, buf[:, 3 * c:])
+        return self.cv2(F_.CatInto.apply(buf, x, y1, y2, y3))
 
 
 class Attention(nn.Module):

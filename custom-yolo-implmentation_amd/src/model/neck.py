@@ -22,9 +22,17 @@ class Neck(nn.Module):
 
     def forward(self, x):
         p3, p4, p5 = x
-        up, cat = F_.Upsample2x.apply, F_.Cat.apply
-        p4 = self.h1(cat(up(p5), p4))
-        p3 = self.h2(cat(up(p4), p3))
-        p4 = self.h4(cat(self.h3(p3), p4))
-        p5 = self.h6(cat(self.h5(p4), p5))
+
+        def joined(head, make_first, skip):
+            """cat(first, skip) for `head`: `first` (an upsample / stride-2 Conv output) is written straight into the
+            concat buffer; `skip` comes from another stage and is copied in by CatInto."""
+            c1 = make_first[1]
+            buf = F_.cat_buffer(skip, head.conv1.conv.weight, c1 + skip.shape[1])
+            first = make_first[0](buf[:, :c1])
+            return head(F_.CatInto.apply(buf, first, skip))
+
+        p4 = joined(self.h1, (lambda o: F_.Upsample2x.apply(p5, o), p5.shape[1]), p4)
+        p3 = joined(self.h2, (lambda o: F_.Upsample2x.apply(p4, o), p4.shape[1]), p3)
+        p4 = joined(self.h4, (lambda o: self.h3(p3, out=o), self.h3.conv.out_channels), p4)
+        p5 = joined(self.h6, (lambda o: self.h5(p4, out=o), self.h5.conv.out_channels), p5)
         return p3, p4, p5

@@ -84,7 +84,9 @@ class TrainStepRunner:
         want_opt = not self.comm and capturable
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: RCCL's watchdog thread polls events of earlier collectives; in the default (global) mode that
+        # query is an error while ANY thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.loss, ld = self._fwd_bwd(images, packed)
             self.scalars = ld._scalars
             if want_opt:
@@ -94,7 +96,7 @@ class TrainStepRunner:
         self.graph, self.opt_in_graph = g, want_opt
         if self.comm and capturable:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g.pool()):
+            with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
                 self._unpack_grads()
                 self.optimizer.step()
             self.graph2 = g2

@@ -56,8 +56,16 @@ def pack_weights(w, k, stride, mode, dtype):
     return w.detach().to(dtype)           # stand-in handle: the OIHW weights rounded to the compute dtype
 
 
-def conv_fwd(x, wp, bias, cout, k, stride, stats_acc=None):
-    y = _nhwc(F.conv2d(x.float(), wp.float(), bias, stride, k // 2).to(x.dtype))
+def _into(out, val):
+    """Producers may be handed their destination (a channel slice of a concat buffer)."""
+    if out is None:
+        return val
+    out.data.copy_(val)       # like the kernels: a raw write, invisible to autograd's version counters
+    return out
+
+
+def conv_fwd(x, wp, bias, cout, k, stride, stats_acc=None, out=None):
+    y = _into(out, _nhwc(F.conv2d(x.float(), wp.float(), bias, stride, k // 2).to(x.dtype)))
     if stats_acc is not None:
         bn_stats_acc(y, stats_acc)
     return y
@@ -171,11 +179,11 @@ def _act_grad(z, act):
     return s * (1 + z * (1 - s))
 
 
-def bn_act_fwd(y, scale, shift, act, res=None):
+def bn_act_fwd(y, scale, shift, act, res=None, out=None):
     z = _act(y.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), act)
     if res is not None:
         z = z + res.float()
-    return _nhwc(z.to(y.dtype))
+    return _into(out, _nhwc(z.to(y.dtype)))
 
 
 def bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act):
@@ -200,9 +208,9 @@ def channel_sum(x):
     return x.float().sum((0, 2, 3))
 
 
-def maxpool5_fwd(x):
-    out, idx = F.max_pool2d(x.float(), 5, 1, 2, return_indices=True)
-    return _nhwc(out.to(x.dtype)), idx
+def maxpool5_fwd(x, out=None):
+    o, idx = F.max_pool2d(x.float(), 5, 1, 2, return_indices=True)
+    return _into(out, _nhwc(o.to(x.dtype))), idx
 
 
 def maxpool5_bwd(dout, idx):
@@ -212,8 +220,8 @@ def maxpool5_bwd(dout, idx):
     return _nhwc(dx.view(n, c, h, w).to(dout.dtype))
 
 
-def upsample2x_fwd(x):
-    return _nhwc(F.interpolate(x.float(), scale_factor=2.0, mode="nearest").to(x.dtype))
+def upsample2x_fwd(x, out=None):
+    return _into(out, _nhwc(F.interpolate(x.float(), scale_factor=2.0, mode="nearest").to(x.dtype)))
 
 
 def upsample2x_bwd(dout):
