@@ -137,11 +137,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("BENCH_ONE_DEVICE"):       # rehearsal of the N > 1 control flow on a one-GPU box (with gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        else:
+            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
 
     from src.hipops import ops
     from src.model.losses import PackedTargets, YoloDFLQFLoss
@@ -160,7 +166,8 @@ def main():
     img, gts = synthetic_batch(args.batch, args.res, nc, 1234 + rank, dev)
     packed = PackedTargets(gts, dev)
     runner = TrainStepRunner(model, crit, opt, "bfloat16", use_graph=not args.no_graph,
-                             grad_comm_dtype=torch.bfloat16 if world > 1 else None)
+                             grad_comm_dtype=(None if os.environ.get("BENCH_COMM_DTYPE") == "fp32" else torch.bfloat16)
+                             if world > 1 else None)
     runner.capture(img, packed)
 
     for _ in range(args.warmup):
@@ -190,7 +197,9 @@ def main():
             torch.cuda.synchronize()
             torch.cuda._sleep(int(1.5e9))            # park the GPU so the host queues the whole step ahead:
             #                                          event pairs then bracket kernel time, not launch latency
-            runner._eager_step(img, packed)          # one instrumented eager step (same kernels, same shapes)
+            opt.zero_grad(set_to_none=True)
+            runner._fwd_bwd(img, packed)             # one instrumented eager fwd+loss+bwd (same kernels and shapes as
+            #                                          the graph; no collective: only rank 0 runs this)
             groups = timer.summary()
         finally:
             timer.remove()

@@ -65,6 +65,23 @@ static inline int hip_status(hipError_t e) { return e == hipSuccess ? YOLO_OK : 
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero fill as a KERNEL.  hipMemsetAsync becomes a memset node when the stream is captured into a hipGraph, and on
+// this stack replays of such a graph did not always order that node before the kernels that accumulate into the
+// buffer (BatchNorm statistics came out wrong from the second replay on, run-dependent).  Kernel nodes of a
+// single-stream capture form a plain chain, so everything the training step zeroes goes through here.
+static __global__ void k_zero_fill(uint32_t* __restrict__ p, size_t nwords) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline int yolo_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return YOLO_OK;
+    if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return hip_status(hipMemsetAsync(p, 0, bytes, st));   // not on the step
+    const size_t nwords = bytes / 4;
+    size_t blocks = (nwords + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, nwords);
+    return YOLO_LAUNCH_CHECK();
+}
+
 // dispatch on the activation dtype code
 #define YOLO_DISPATCH_T(dtype, ...)                                   \
     switch (dtype) {                                                  \

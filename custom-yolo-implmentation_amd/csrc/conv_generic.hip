@@ -450,7 +450,7 @@ int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws
     if (algo == 2) return YOLO_ERR_ARG;
     // single packed matrix accumulated with atomics, then unpacked
     float* dwp = ws;
-    int rc = hip_status(hipMemsetAsync(dwp, 0, (size_t)Cout * Kpad * sizeof(float), st));
+    int rc = yolo_zero_async(dwp, (size_t)Cout * Kpad * sizeof(float), st);
     if (rc) return rc;
     if (path == 3) {
         rc = mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);

@@ -311,7 +311,7 @@ int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, 
     ClsFilter filt;
     filt.n = n_classes;
     for (int k = 0; k < n_classes; ++k) filt.ids[k] = classes[k];
-    int rc = hip_status(hipMemsetAsync(overflow, 0, 4, st));
+    int rc = yolo_zero_async(overflow, 4, st);
     if (rc) return rc;
     YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_candidates<T>), dim3(bs), dim3(256), 0, st, (const T*)y, nc, M, conf_thres,
                                               multi_label, filt, cap, rows, count, overflow));

@@ -749,7 +749,7 @@ int nhwc_to_ncm_out(const void* src, int ld, void* dst, int dst_dtype, long sn, 
 
 extern "C" {
 
-int yolo_memset0(void* p, size_t bytes, hipStream_t st) { return hip_status(hipMemsetAsync(p, 0, bytes, st)); }
+int yolo_memset0(void* p, size_t bytes, hipStream_t st) { return yolo_zero_async(p, bytes, st); }
 
 int yolo_ncm_to_nhwc(const void* src, int src_dtype, long sn, long sc, long off, void* dst, int dst_dtype,
                      int ld, int N, int C, int HW, hipStream_t st) {

@@ -316,7 +316,7 @@ int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* stride
         int nblk = (int)((elems / (vec ? VV : 1) + 255) / 256);
         if (nblk > DENSE_BLOCKS) nblk = DENSE_BLOCKS;
         if (nblk < 1) nblk = 1;
-        int rc = hip_status(hipMemsetAsync(partial, 0, DENSE_BLOCKS * sizeof(double), st));
+        int rc = yolo_zero_async(partial, DENSE_BLOCKS * sizeof(double), st);
         if (rc) return rc;
         if (vec) hipLaunchKernelGGL((k_dense<T, VV>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial);
         else hipLaunchKernelGGL((k_dense<T, 1>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial);

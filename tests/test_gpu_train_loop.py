@@ -86,3 +86,30 @@ def test_two_graph_data_parallel_step_equals_single_graph_step(pg):
         assert (a - b).abs().max() / scale < 1e-3, "pack / all-reduce / unpack changed the gradients"
         assert (a - c).abs().max() / scale < 1e-2, "bf16-compressed exchange outside bf16 rounding"
     assert any(not torch.equal(a, c) for a, c in zip(base, comp))
+
+
+def test_graph_replays_reproduce_the_eager_forward():
+    """A captured forward must give the eager result on EVERY replay.  (Regression: the statistics accumulators were
+    zeroed by hipMemsetAsync, which a capture turns into a memset node; replays did not always order it before the
+    kernels accumulating into the buffer, so BatchNorm went wrong from the second replay on.  Everything the step
+    zeroes now goes through a zero-fill kernel.)"""
+    from src.model.model_builder import Model
+    torch.manual_seed(0)
+    model = Model(**NANO, num_classes=80).cuda().train()
+    model.prepack = True
+    img = torch.randn(2, 3, 160, 160, generator=torch.Generator().manual_seed(5)).cuda()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(2):
+            ref = model(img)[0].float().clone()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        out = model(img)[0]
+    for i in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        err = float((out.float() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-4, f"replay {i}: {err}"
