@@ -229,13 +229,15 @@ __global__ void k_dw3x3_wgrad(const T* __restrict__ x, int ldx, const T* __restr
 #pragma unroll
         for (int j = 0; j < V; ++j) red[threadIdx.x][j] = acc[t][j];
         __syncthreads();
-        if (wl == 0 && cg < cv) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                float s = 0.f;
-                for (int rr = 0; rr < rpb; ++rr) s += red[threadIdx.x + rr * tpr][j];
-                part[(long)(cg * V + j) * 9 + t] = s;
-            }
+        // one thread per (channel group, lane value): tpr*V sums over the workgroup's rpb row lanes, in parallel
+        // (a single lane row walking all of them serially cost tens of microseconds per workgroup on narrow layers)
+        for (int o = threadIdx.x; o < tpr * V; o += 256) {
+            const int cl = o / V, j = o - cl * V;
+            const int cgo = blockIdx.y * tpr + cl;
+            float s = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < rpb; ++rr) s += red[rr * tpr + cl][j];
+            if (cgo < cv) part[(long)(cgo * V + j) * 9 + t] = s;
         }
     }
 }
