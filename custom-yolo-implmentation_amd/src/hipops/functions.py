@@ -30,6 +30,29 @@ def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
+_SIDE = {}
+OVERLAP_WGRAD = True        # run a conv's weight gradient on a side stream, concurrently with its data gradient
+
+
+def _wgrad_overlapped(x, dy, k, stride, w_dtype, dgrad_fn):
+    """(dx, dw) of a dense conv.  The two gradients are independent: the weight gradient is issued on a side HIP
+    stream (fork after dy is ready, join before returning), so on the small maps -- kernels of 100-400 workgroups on
+    a 256-CU chip -- the two run side by side; inside a captured step this becomes a fork/join in the hipGraph."""
+    if not (OVERLAP_WGRAD and x.is_cuda):
+        return dgrad_fn(), ops.conv_wgrad(x, dy, k, stride, w_dtype)
+    cur = torch.cuda.current_stream(x.device)
+    side = _SIDE.get(x.device)
+    if side is None:
+        side = _SIDE[x.device] = torch.cuda.Stream(x.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        dw = ops.conv_wgrad(x, dy, k, stride, w_dtype)
+    dx = dgrad_fn()
+    cur.wait_stream(side)
+    dw.record_stream(cur)           # allocated on the side stream, consumed (optimizer / reducer) on this one
+    return dx, dw
+
+
 class BnArena:
     """Per-forward pool of zeroed BatchNorm accumulators: ONE memset covers every layer of a model pass.
     A fresh pool per Model.forward keeps un-backpropagated passes independent (the autograd graph keeps
@@ -124,9 +147,12 @@ class ConvBnAct(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = ops.dw_wgrad(x, dy).to(weight.dtype)
         else:
-            if ctx.needs_input_grad[0]:
-                dx = ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride)
-            if ctx.needs_input_grad[1]:
+            dgrad = lambda: ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride)
+            if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+                dx, dw = _wgrad_overlapped(x, dy, k, stride, weight.dtype, dgrad)
+            elif ctx.needs_input_grad[0]:
+                dx = dgrad()
+            elif ctx.needs_input_grad[1]:
                 dw = ops.conv_wgrad(x, dy, k, stride, weight.dtype)
         if dgamma is not None and ctx.needs_input_grad[2]:
             dgamma, dbeta = dgamma.to(gdtype), dbeta.to(gdtype)
