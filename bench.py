@@ -161,8 +161,13 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     crit = YoloDFLQFLoss(num_classes=nc, lambda_box=1.5, lambda_cls=1.0)
-    # fused multi-tensor AdamW: the non-fused capturable form issues ~500 per-parameter scalar kernels per step
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True, fused=True)
+    # one-launch AdamW (src/training/fused_adamw.py); BENCH_TORCH_ADAMW=1 selects torch's fused
+    # multi-tensor AdamW (12 launches per step) for A/B runs
+    if os.environ.get("BENCH_TORCH_ADAMW"):
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True, fused=True)
+    else:
+        from src.training.fused_adamw import HipAdamW
+        opt = HipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
     img, gts = synthetic_batch(args.batch, args.res, nc, 1234 + rank, dev)
     packed = PackedTargets(gts, dev)
     runner = TrainStepRunner(model, crit, opt, "bfloat16", use_graph=not args.no_graph,

@@ -1,0 +1,133 @@
+// AdamW step of ALL parameters in one launch.
+// torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps added to sqrt(v)/sqrt(bc2)):
+//   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// A device job table lists (param, grad, exp_avg, exp_avg_sq, numel) per tensor; one workgroup owns one 4096-element
+// chunk of one tensor (job found once per workgroup).  Hyper-parameters and the step counter live in device memory so
+// a captured step follows a learning-rate schedule without recapture; GradScaler's scale / found_inf pair is
+// honoured like torch's fused optimizers do (skip the whole step on overflow, unscale the gradient in flight).
+#include "common.h"
+
+struct AdamJob {
+    void* p;            // parameter, p_dtype
+    const void* g;      // gradient, g_dtype
+    float* m;           // exp_avg (fp32)
+    float* v;           // exp_avg_sq (fp32)
+    long n;             // elements
+    long cstart;        // first 4096-element chunk (= workgroup) of this job
+    int p_dtype, g_dtype;
+};
+
+namespace {
+
+constexpr int CHUNK = 4096;
+
+template <typename P> __device__ __forceinline__ float ldf(const void* p, long i) { return to_f<P>(((const P*)p)[i]); }
+__device__ __forceinline__ float ld_any(const void* p, int dt, long i) {
+    return dt == YOLO_F32 ? ldf<float>(p, i) : dt == YOLO_BF16 ? ldf<bf16_t>(p, i) : ldf<f16_t>(p, i);
+}
+__device__ __forceinline__ void st_any(void* p, int dt, long i, float x) {
+    if (dt == YOLO_F32) ((float*)p)[i] = x;
+    else if (dt == YOLO_BF16) ((bf16_t*)p)[i] = from_f<bf16_t>(x);
+    else ((f16_t*)p)[i] = from_f<f16_t>(x);
+}
+
+// step += 1 unless the scaler found an overflow (one thread; the main kernel reads the updated value)
+__global__ void k_adamw_tick(float* __restrict__ step, const float* __restrict__ found_inf) {
+    if (found_inf == nullptr || *found_inf == 0.f) *step += 1.f;
+}
+
+// hyper = [lr, beta1, beta2, eps, weight_decay] as DOUBLES: 1 - beta and the bias corrections are formed in double
+// like torch does on the host (1 - 0.999 in fp32 is off by 5e-5 relative, which shows in exp_avg_sq)
+__global__ __launch_bounds__(256) void k_adamw(const AdamJob* __restrict__ jobs, int njobs, const double* __restrict__ hyper,
+                                               const float* __restrict__ step, const float* __restrict__ grad_scale,
+                                               const float* __restrict__ found_inf) {
+    if (found_inf != nullptr && *found_inf != 0.f) return;
+    __shared__ int sj;
+    __shared__ float sc[7];                     // b1, 1-b1, b2, 1-b2, step_size, 1/sqrt(bc2), decay
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {                       // last job with cstart <= blockIdx.x
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].cstart <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        sj = lo;
+        const double lr = hyper[0], b1d = hyper[1], b2d = hyper[2], wd = hyper[4], t = (double)*step;
+        const double bc1 = 1.0 - pow(b1d, t), bc2 = 1.0 - pow(b2d, t);
+        sc[0] = (float)b1d; sc[1] = (float)(1.0 - b1d); sc[2] = (float)b2d; sc[3] = (float)(1.0 - b2d);
+        sc[4] = (float)(lr / bc1); sc[5] = (float)sqrt(bc2); sc[6] = (float)(1.0 - lr * wd);
+    }
+    __syncthreads();
+    const AdamJob j = jobs[sj];
+    const float b1 = sc[0], omb1 = sc[1], b2 = sc[2], omb2 = sc[3], step_size = sc[4], bc2s = sc[5], decay = sc[6];
+    const float eps = (float)hyper[3];
+    const float gs = grad_scale ? 1.f / *grad_scale : 1.f;      // GradScaler: gradients arrive multiplied by the scale
+    const long base = ((long)blockIdx.x - j.cstart) * CHUNK;
+    if (j.p_dtype == YOLO_F32 && j.g_dtype == YOLO_F32 && (j.n & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(j.p) | reinterpret_cast<uintptr_t>(j.g) | reinterpret_cast<uintptr_t>(j.m) |
+          reinterpret_cast<uintptr_t>(j.v)) & 15) == 0) {
+        // the common case: fp32 master weights and gradients, 16-byte packets
+        for (long i = base + threadIdx.x * 4L; i < base + CHUNK && i < j.n; i += 256 * 4) {
+            float4 p = *reinterpret_cast<float4*>((float*)j.p + i);
+            const float4 g = *reinterpret_cast<const float4*>((const float*)j.g + i);
+            float4 m = *reinterpret_cast<float4*>(j.m + i), v = *reinterpret_cast<float4*>(j.v + i);
+            float* pp = &p.x; const float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gg = gp[k] * gs;
+                mp[k] = b1 * mp[k] + omb1 * gg;
+                vp[k] = b2 * vp[k] + omb2 * gg * gg;
+                pp[k] = pp[k] * decay - step_size * mp[k] / (sqrtf(vp[k]) / bc2s + eps);
+            }
+            *reinterpret_cast<float4*>((float*)j.p + i) = p;
+            *reinterpret_cast<float4*>(j.m + i) = m;
+            *reinterpret_cast<float4*>(j.v + i) = v;
+        }
+        return;
+    }
+    for (long i = base + threadIdx.x; i < base + CHUNK && i < j.n; i += 256) {
+        const float gg = ld_any(j.g, j.g_dtype, i) * gs;
+        const float m = b1 * j.m[i] + omb1 * gg;
+        const float v = b2 * j.v[i] + omb2 * gg * gg;
+        j.m[i] = m;
+        j.v[i] = v;
+        st_any(j.p, j.p_dtype, i, ld_any(j.p, j.p_dtype, i) * decay - step_size * m / (sqrtf(v) / bc2s + eps));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int yolo_adamw_job_bytes(void) { return (int)sizeof(AdamJob); }
+
+// write record `index` of the host-side table
+int yolo_adamw_job_fill(void* jobs_host, int index, void* p, int p_dtype, const void* g, int g_dtype, float* m, float* v,
+                        long n) {
+    if (n < 0) return YOLO_ERR_ARG;
+    AdamJob& j = ((AdamJob*)jobs_host)[index];
+    j.p = p; j.g = g; j.m = m; j.v = v; j.n = n; j.cstart = 0; j.p_dtype = p_dtype; j.g_dtype = g_dtype;
+    return YOLO_OK;
+}
+
+// assign the chunk ranges; returns the number of workgroups
+long yolo_adamw_jobs_finalize(void* jobs_host, int njobs) {
+    AdamJob* jobs = (AdamJob*)jobs_host;
+    long c = 0;
+    for (int i = 0; i < njobs; ++i) {
+        jobs[i].cstart = c;
+        long nch = (jobs[i].n + CHUNK - 1) / CHUNK;
+        c += nch > 0 ? nch : 1;
+    }
+    return c;
+}
+
+int yolo_adamw_step(const void* jobs_dev, int njobs, long nchunks, const double* hyper, float* step, const float* grad_scale,
+                    const float* found_inf, hipStream_t st) {
+    if (njobs <= 0 || nchunks <= 0) return YOLO_OK;
+    hipLaunchKernelGGL(k_adamw_tick, dim3(1), dim3(1), 0, st, step, found_inf);
+    hipLaunchKernelGGL(k_adamw, dim3((unsigned)nchunks), dim3(256), 0, st, (const AdamJob*)jobs_dev, njobs, hyper, step,
+                       grad_scale, found_inf);
+    return YOLO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+"""AdamW over every parameter in ONE kernel launch: `HipAdamW`, a drop-in for the
+`torch.optim.AdamW` that the reference's get_optimizer builds (src/training/utils_train.py:34; step at
+src/training/train_model.py:247-253).
+
+* same update rule, defaults, `param_groups` keys and per-parameter state names (`step`, `exp_avg`, `exp_avg_sq`),
+  so `ReduceLROnPlateau`, checkpoints (`state_dict` / `load_state_dict`) and `GradScaler.step` work unchanged;
+* hyper-parameters and the step counter live in device memory: a captured step follows a learning-rate schedule
+  without recapture (`sync_hyper()` copies changed values; `step()` calls it when not capturing);
+* the kernel reads a device job table (parameter / gradient / moment pointers).  Gradient tensors are re-created by
+  autograd every eager step, so the table is rebuilt when a pointer changed; inside a graph capture the pointers are
+  final but an upload cannot be captured safely, so `step()` only records the launch and `finish_capture()` -- called
+  by TrainStepRunner after the capture -- uploads the table once.
+There is no CPU path: parameters must live on the GPU (like every op of this package).
+"""
+import torch
+
+from src.hipops import lib
+from src.hipops.ops import _p, _stream, dt
+
+
+class HipAdamW(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True      # GradScaler hands over grad_scale / found_inf instead of unscaling itself
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=True):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameter")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=True, differentiable=False, fused=True)
+        super().__init__(params, defaults)
+        self._plans = {}                    # group index -> dict(ptrs, jobs_dev, njobs, nchunks, hyper, hyper_host, step)
+        self._pending = []                  # (jobs_dev, pinned host table) awaiting upload after a capture
+        self.grad_scale = None
+        self.found_inf = None
+
+    # ------------------------------------------------------------------------------------------ state
+    def _init_state(self, group, gi):
+        plan = self._plans.get(gi)
+        if plan is None:
+            dev = next(p.device for p in group["params"])
+            plan = self._plans[gi] = dict(ptrs=None, jobs_dev=None, host=None, njobs=0, nchunks=0, hyper_host=None,
+                                          hyper=torch.zeros(5, dtype=torch.float64, device=dev),
+                                          step=torch.zeros((), dtype=torch.float32, device=dev))
+        for p in group["params"]:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = plan["step"]                           # one shared device counter per group
+                st["exp_avg"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+                st["exp_avg_sq"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+            elif st["step"] is not plan["step"]:                    # after load_state_dict: adopt the loaded count
+                plan["step"].copy_(torch.as_tensor(st["step"], dtype=torch.float32).reshape(()))
+                st["step"] = plan["step"]
+                st["exp_avg"] = st["exp_avg"].to(torch.float32)
+                st["exp_avg_sq"] = st["exp_avg_sq"].to(torch.float32)
+        return plan
+
+    def sync_hyper(self):
+        """Copy changed hyper-parameters (e.g. a scheduler's new lr) to the device; call between graph replays."""
+        for gi, group in enumerate(self.param_groups):
+            plan = self._plans.get(gi)
+            if plan is None:
+                continue
+            want = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                    float(group["weight_decay"]))
+            if plan["hyper_host"] != want:
+                plan["hyper"].copy_(torch.tensor(want, dtype=torch.float64))
+                plan["hyper_host"] = want
+
+    def finish_capture(self):
+        """Upload the job tables recorded while a graph was being captured (call once after the capture ends)."""
+        for dev_t, host_t in self._pending:
+            dev_t.copy_(host_t)
+        self._pending = []
+        self.sync_hyper()
+
+    # ------------------------------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            if group.get("amsgrad") or group.get("maximize"):
+                raise RuntimeError("HipAdamW implements plain AdamW (amsgrad=False, maximize=False)")
+            plan = self._init_state(group, gi)
+            capturing = torch.cuda.is_current_stream_capturing()
+            ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+            if plan["ptrs"] != ptrs:
+                self._build(plan, params, capturing)
+                plan["ptrs"] = ptrs
+            if not capturing:
+                self.sync_hyper()
+            elif plan["hyper_host"] is None:
+                raise RuntimeError("HipAdamW: run one eager step (or sync_hyper()) before capturing a graph")
+            lib.call("yolo_adamw_step", _p(plan["jobs_dev"]), plan["njobs"], plan["nchunks"], _p(plan["hyper"]),
+                     _p(plan["step"]), _p(self.grad_scale), _p(self.found_inf), _stream(params[0]))
+        return loss
+
+    def _build(self, plan, params, capturing):
+        jb = lib.query("yolo_adamw_job_bytes")
+        n = len(params)
+        if plan["host"] is None or plan["host"].numel() != n * jb:
+            if capturing:
+                raise RuntimeError("HipAdamW: run one eager step before capturing a graph (host/device tables are "
+                                   "allocated there)")
+            plan["host"] = torch.zeros(n * jb, dtype=torch.uint8).pin_memory()
+            plan["jobs_dev"] = torch.empty(n * jb, dtype=torch.uint8, device=params[0].device)
+        host = plan["host"]
+        for i, p in enumerate(params):
+            if not (p.is_contiguous() and p.grad.is_contiguous()):
+                raise RuntimeError("HipAdamW needs contiguous parameters and gradients")
+            st = self.state[p]
+            lib.call("yolo_adamw_job_fill", host.data_ptr(), i, _p(p), dt(p), _p(p.grad), dt(p.grad), _p(st["exp_avg"]),
+                     _p(st["exp_avg_sq"]), p.numel())
+        plan["nchunks"] = lib.query("yolo_adamw_jobs_finalize", host.data_ptr(), n)
+        plan["njobs"] = n
+        if capturing:
+            # the pointers recorded now are the capture's final ones; the upload itself must not be captured
+            # (and is not needed until the first replay): finish_capture() does it
+            self._pending.append((plan["jobs_dev"], host))
+        else:
+            plan["jobs_dev"].copy_(host)

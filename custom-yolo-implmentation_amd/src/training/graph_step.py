@@ -94,12 +94,15 @@ class TrainStepRunner:
             elif self.comm:
                 self._pack_grads()
         self.graph, self.opt_in_graph = g, want_opt
+        finish = getattr(self.optimizer, "finish_capture", None)     # HipAdamW: upload the job table recorded in capture
         if self.comm and capturable:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
                 self._unpack_grads()
                 self.optimizer.step()
             self.graph2 = g2
+        if finish is not None:
+            finish()
         return self
 
     # ---- flat communication buffer (world > 1, graph mode): gradients are static tensors after capture
@@ -132,6 +135,9 @@ class TrainStepRunner:
             loss, ld = self._eager_step(images, packed)
             self.scalars = ld._scalars
             return loss
+        sync = getattr(self.optimizer, "sync_hyper", None)    # HipAdamW: a scheduler may have changed lr on the host
+        if sync is not None:
+            sync()
         self.graph.replay()
         if self.opt_in_graph:
             return self.loss

@@ -55,6 +55,14 @@ int yolo_pack_job_count(int stride, int mode);
 long yolo_pack_job_fill(void* jobs_host, const void* w, int w_dtype, void* out, int out_elem_bytes, int O, int I, int k, int stride, int mode, long start);
 long yolo_pack_jobs_finalize(void* jobs_host, int njobs);
 int yolo_pack_batched(const void* jobs_dev, int njobs, long nchunks, int out_dtype, hipStream_t st);
+/* ---- optimizer: torch.optim.AdamW over all parameters in one launch; replaces torch's multi-tensor
+   AdamW (reference: src/training/utils_train.py:34 get_optimizer, src/training/train_model.py:247-253 step).
+   jobs: device copy of a host table of yolo_adamw_job_bytes() records; hyper = [lr, beta1, beta2, eps, weight_decay] (doubles)
+   and step (one float, incremented here) live in device memory; grad_scale / found_inf: GradScaler protocol or null. */
+int yolo_adamw_job_bytes();
+int yolo_adamw_job_fill(void* jobs_host, int index, void* p, int p_dtype, const void* g, int g_dtype, float* m, float* v, long n);
+long yolo_adamw_jobs_finalize(void* jobs_host, int njobs);
+int yolo_adamw_step(const void* jobs_dev, int njobs, long nchunks, const double* hyper, float* step, const float* grad_scale, const float* found_inf, hipStream_t st);
 int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
 long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo);
