@@ -96,7 +96,8 @@ class HipAdamW(torch.optim.Optimizer):
             elif plan["hyper_host"] is None:
                 raise RuntimeError("HipAdamW: run one eager step (or sync_hyper()) before capturing a graph")
             lib.call("yolo_adamw_step", _p(plan["jobs_dev"]), plan["njobs"], plan["nchunks"], _p(plan["hyper"]),
-                     _p(plan["step"]), _p(self.grad_scale), _p(self.found_inf), _stream(params[0]))
+                     _p(plan["step"]), _p(getattr(self, "grad_scale", None)), _p(getattr(self, "found_inf", None)),
+                     _stream(params[0]))      # GradScaler sets the two attributes around step() and deletes them after
         return loss
 
     def _build(self, plan, params, capturing):

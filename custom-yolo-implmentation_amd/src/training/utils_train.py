@@ -24,8 +24,17 @@ _LOWP = ("bfloat16", "float16")
 
 def get_optimizer(model: nn.Module, lr: float, weight_decay: float, patience: int, factor: float
                   ) -> Tuple[optim.Optimizer, optim.lr_scheduler.ReduceLROnPlateau]:
-    """AdamW + ReduceLROnPlateau (reference :20-36)."""
-    opt = optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+    """AdamW + ReduceLROnPlateau (reference :20-36).  Plain GPU parameters (single GPU, DDP) get the one-launch
+    `HipAdamW` (same update rule, state names and scheduler / GradScaler / checkpoint behaviour as torch.optim.AdamW,
+    whose default eager form issues several small kernels per parameter); sharded parameters (FSDP flat parameters,
+    FSDP2 DTensors) keep torch.optim.AdamW."""
+    params = list(model.parameters())
+    plain = params and all(type(p) is nn.Parameter and p.is_cuda for p in params)
+    if plain:
+        from src.training.fused_adamw import HipAdamW
+        opt = HipAdamW(params, lr=lr, weight_decay=weight_decay)
+    else:
+        opt = optim.AdamW(params, lr=lr, weight_decay=weight_decay)
     return opt, optim.lr_scheduler.ReduceLROnPlateau(opt, patience=patience, factor=factor)
 
 

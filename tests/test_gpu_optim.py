@@ -51,7 +51,7 @@ def test_grad_scaler_protocol_and_state_dict_round_trip():
     _set_grads(a, 8, 1024.0)
     oa.found_inf = torch.ones(1, device="cuda")
     oa.step()
-    oa.grad_scale = oa.found_inf = None
+    del oa.grad_scale, oa.found_inf          # what GradScaler.step does after the call
     for x, y, z in zip(a, b, before):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-6) and torch.equal(x, z)
     assert float(oa.state[a[0]]["step"]) == 1
