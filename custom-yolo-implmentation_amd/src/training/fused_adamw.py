@@ -29,8 +29,8 @@ class HipAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._plans = {}                    # group index -> dict(ptrs, jobs_dev, njobs, nchunks, hyper, hyper_host, step)
         self._pending = []                  # (jobs_dev, pinned host table) awaiting upload after a capture
-        self.grad_scale = None
-        self.found_inf = None
+        # grad_scale / found_inf are NOT pre-defined: GradScaler.step multiplies an existing grad_scale attribute in,
+        # sets both around step() and deletes them afterwards
 
     # ------------------------------------------------------------------------------------------ state
     def _init_state(self, group, gi):

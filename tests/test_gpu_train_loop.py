@@ -19,7 +19,7 @@ def pg():
     cleanup_distribute_mode()
 
 
-@pytest.mark.parametrize("mode,precision", [("ddp", "bfloat16"), ("ddp", "float32"), ("fsdp2", "bfloat16")])
+@pytest.mark.parametrize("mode,precision", [("ddp", "bfloat16"), ("ddp", "float32"), ("ddp", "float16"), ("fsdp2", "bfloat16")])
 def test_train_one_epoch_like_the_script(pg, mode, precision, tmp_path):
     from src.data.data_loader import get_data_loaders
     from src.model.losses import YoloDFLQFLoss
