@@ -1,4 +1,4 @@
-"""TEMP: time single conv layers through the C-ABI (YOLO_CONV_DBG ablation bits are read by the library)."""
+"""TEMP: time single conv layers through the C-ABI (standalone timing of single conv layers)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "custom-yolo-implmentation_amd"))
@@ -19,7 +19,7 @@ def run(n, cin, h, w, cout, k, s, reps=int(os.environ.get("REPS", "20"))):
     oh, ow = y.shape[2], y.shape[3]
     fl = 2.0 * n * oh * ow * cout * cin * k * k
     by = x.numel() * 2 + y.numel() * 2
-    print(f"dbg={os.environ.get('YOLO_CONV_DBG','0'):>2s} ({n},{cin},{h},{w})->{cout} k{k}s{s}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s {by/us/1e3:7.0f} GB/s", flush=True)
+    print(f"({n},{cin},{h},{w})->{cout} k{k}s{s}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s {by/us/1e3:7.0f} GB/s", flush=True)
 
 for shp in [(32,128,160,160,128,3,2), (32,64,160,160,64,3,1), (32,96,160,160,128,1,1), (32,256,80,80,256,3,2), (32,32,320,320,32,1,1)]:
     run(*shp)
