@@ -34,6 +34,7 @@ struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic i
     int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, Hg, Wg, ostep, ooff_h, ooff_w, sstride, ntaps, KT, Kpad;
     unsigned dh_pack, dw_pack;   // 2 bits per tap: value + 1
     int tap_inner;               // MODE 2 K order: 1 = taps innermost, 0 = channel chunks innermost
+    int dma;                     // MODE 2 -> 3: tiles go global -> LDS by LDS-DMA instead of through registers
     float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
 };
 
@@ -43,6 +44,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// LDS-DMA: 16 bytes per lane from a buffer descriptor straight into LDS at lds_base + 16*lane (wave-uniform base).
+// Wrapped so that the host compilation pass never sees the device-only builtin.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, void* lds_base, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset, 0, 0);
+#endif
 }
 
 // x + (x rotated by N lanes inside its row of 16): one VALU op (v_add_f32 with a DPP operand)
@@ -65,6 +74,7 @@ inline GeomDev to_dev(const ConvGeom& g) {
     d.dh_pack = d.dw_pack = 0;
     d.stats = g.stats;
     d.tap_inner = 0;
+    d.dma = 1;      // LDS-DMA staging: level or a few % ahead of register staging on every shape of tools/conv_tune.py
     for (int t = 0; t < g.ntaps; ++t) {
         d.dh_pack |= (unsigned)(g.dh[t] + 1) << (2 * t);
         d.dw_pack |= (unsigned)(g.dw[t] + 1) << (2 * t);

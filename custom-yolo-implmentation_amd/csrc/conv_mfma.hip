@@ -33,6 +33,10 @@ namespace {
 //   for the whole loop, the step's tap / chunk / weight-column offset is one scalar (soffset), and a padding tap
 //   or a row past the end is a voffset beyond the descriptor's range, which the hardware reads as zero -- the
 //   gather costs 3 vector instructions per row and step.  All sizes are below 2^30 elements (host check).
+// MODE 3: MODE 2 with LDS-DMA (buffer_load_dwordx4 ... lds): the tiles go global -> LDS without passing through
+//   registers (no ds_write pass, 16 fewer VGPRs).  A wave instruction writes 64 x 16 B contiguously, which is exactly
+//   16 rows of the swizzled 64-byte-row image when the lane in slot s of a row fetches chunk s ^ swizzle(row);
+//   out-of-range lanes write zeros (tests/test_gpu_selftest.py pins both facts).
 template <typename T, int WGM, int WGN, int WM, int WN, bool ACC, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conv_mfma(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
                                                    const float* __restrict__ bias, T* __restrict__ dst, int ntile_n) {
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     int ltap = 0, ch = kseg * 8;
     const T* wrow[WR];
 
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
         for (int t = 0; t < g.ntaps; ++t) {
             const int dh = (int)((g.dh_pack >> (2 * t)) & 3u) - 1, dw = (int)((g.dw_pack >> (2 * t)) & 3u) - 1;
 #pragma unroll
@@ -100,11 +104,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src) - shift, 0, (g.N * g.Hs * g.Ws * g.lds + shift) * 2,
                                                 0x00020000);
         rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wm), 0, g.Cd * g.Kpad * 2, 0x00020000);
+        // register staging: this thread loads chunk kseg and stores it at the swizzled slot; LDS-DMA: the lane's
+        // slot is fixed (lane-linear image), so it loads the chunk that belongs there
+        const int kload = MODE == 3 ? (kseg ^ ((-(lrow >> 2)) & 3)) : kseg;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) voffa[i] = (rowoff[i] + kseg * 8) * 2;
+        for (int i = 0; i < 2; ++i) voffa[i] = (rowoff[i] + kload * 8) * 2;
 #pragma unroll
         for (int i = 0; i < WR; ++i)
-            voffb[i] = wvalid[i] ? ((cd0 + lrow + i * 64) * g.Kpad + kseg * 8) * 2 : (int)0x80000000;
+            voffb[i] = wvalid[i] ? ((cd0 + lrow + i * 64) * g.Kpad + kload * 8) * 2 : (int)0x80000000;
     } else {
 #pragma unroll
         for (int i = 0; i < WR; ++i) wrow[i] = wm + (long)(cd0 + (wvalid[i] ? lrow + i * 64 : 0)) * g.Kpad + kseg * 8;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 
     auto gload = [&](int kt) {
-        if constexpr (MODE == 2) {
+        if constexpr (MODE >= 2) {
             const int soff = ((int)((g.dh_pack >> (2 * tap)) & 3u) * g.Ws + (int)((g.dw_pack >> (2 * tap)) & 3u)) * g.lds + cbase;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -154,6 +161,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             else if (ch >= g.Cs) { ch -= g.Cs; ++ltap; }
         }
     };
+    // MODE 3: the same step as one LDS-DMA instruction per 16-row group (wave w: rows 16w.. and 64+16w..)
+    auto gload_dma = [&](int buf) {
+        const int soff = ((int)((g.dh_pack >> (2 * tap)) & 3u) * g.Ws + (int)((g.dw_pack >> (2 * tap)) & 3u)) * g.lds + cbase;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int vo = ((vmask[i] >> tap) & 1u) ? voffa[i] : (int)0x80000000;
+            lds_dma16(rsa, &lds_a[buf][wave * 16 + i * 64][0], vo, soff * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            if (BN >= (i + 1) * 64 || wave * 16 + i * 64 < BN)
+                lds_dma16(rsb, &lds_b[buf][wave * 16 + i * 64][0], voffb[i], wcol * 2);
+        if (g.tap_inner) {
+            ++tap;
+            wcol += g.Cs;
+            if (tap == g.ntaps) { tap = 0; cbase += BK; wcol += BK - g.ntaps * g.Cs; }
+        } else {
+            cbase += BK;
+            wcol += BK;
+            if (cbase == g.Cs) { cbase = 0; ++tap; }
+        }
+    };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -174,23 +203,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < g.KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < g.KT) gload(kt + 1);
-        frag fa[WN], fb[WM];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) fa[j] = *reinterpret_cast<const frag*>(&lds_b[buf][crow + j * 16 + fr][fk]);
-#pragma unroll
-        for (int i = 0; i < WM; ++i) fb[i] = *reinterpret_cast<const frag*>(&lds_a[buf][prow + i * 16 + fr][fk]);
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) acc[i][j] = ops::mma(fa[j], fb[i], acc[i][j]);
-        if (kt + 1 < g.KT) lstore(buf ^ 1);
+    if constexpr (MODE == 3) {
+        gload_dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kt = 0; kt < g.KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < g.KT) gload_dma(buf ^ 1);      // the other stage was last read before the previous barrier
+            frag fa[WN], fb[WM];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) fa[j] = *reinterpret_cast<const frag*>(&lds_b[buf][crow + j * 16 + fr][fk]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) fb[i] = *reinterpret_cast<const frag*>(&lds_a[buf][prow + i * 16 + fr][fk]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = ops::mma(fa[j], fb[i], acc[i][j]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < g.KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < g.KT) gload(kt + 1);
+            frag fa[WN], fb[WM];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) fa[j] = *reinterpret_cast<const frag*>(&lds_b[buf][crow + j * 16 + fr][fk]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) fb[i] = *reinterpret_cast<const frag*>(&lds_a[buf][prow + i * 16 + fr][fk]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = ops::mma(fa[j], fb[i], acc[i][j]);
+            if (kt + 1 < g.KT) lstore(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds channels cbase..cbase+3 of pixel (tile pixel i*16 + fr).  The first pixel's
@@ -384,12 +434,13 @@ void launch_tile(const GeomDev& d, const void* src, const void* wm, const float*
     long pix = (long)d.N * d.Hg * d.Wg;
     int tm = (int)((pix + BM - 1) / BM), tn = (d.Cd + BN - 1) / BN;
     dim3 grid(tm * tn);
-    const int mode = d.Cs < BK ? 1 : (d.Cs % BK == 0 ? 2 : 0);
+    int mode = d.Cs < BK ? 1 : (d.Cs % BK == 0 ? 2 : 0);
+    if (mode == 2 && d.dma) mode = 3;
 #define CONV_LAUNCH(ACC_, SM_)                                                                                        \
     hipLaunchKernelGGL((k_conv_mfma<T, WGM, WGN, WM, WN, ACC_, SM_>), grid, dim3(256), 0, st, d, (const T*)src,       \
                        (const T*)wm, bias, (T*)dst, tn)
-    if (accumulate) { if (mode == 1) CONV_LAUNCH(true, 1); else if (mode == 2) CONV_LAUNCH(true, 2); else CONV_LAUNCH(true, 0); }
-    else { if (mode == 1) CONV_LAUNCH(false, 1); else if (mode == 2) CONV_LAUNCH(false, 2); else CONV_LAUNCH(false, 0); }
+    if (accumulate) { if (mode == 1) CONV_LAUNCH(true, 1); else if (mode == 2) CONV_LAUNCH(true, 2); else if (mode == 3) CONV_LAUNCH(true, 3); else CONV_LAUNCH(true, 0); }
+    else { if (mode == 1) CONV_LAUNCH(false, 1); else if (mode == 2) CONV_LAUNCH(false, 2); else if (mode == 3) CONV_LAUNCH(false, 3); else CONV_LAUNCH(false, 0); }
 #undef CONV_LAUNCH
 }
 
@@ -407,11 +458,12 @@ void launch_conv_t(const GeomDev& d_in, const void* src, const void* wm, const f
     if (bn == 128 && d_in.ntaps == 1 && src_bytes <= (128L << 20)) bn = 64;
     while (bn > 32 && blocks(bn) < 256) bn >>= 1;
     GeomDev d = d_in;
-    if (const char* e = getenv("YOLO_CONV_TUNE")) {          // "bn,tap_inner": tuning runs only
-        int v[2] = {0, -1};
-        sscanf(e, "%d,%d", &v[0], &v[1]);
+    if (const char* e = getenv("YOLO_CONV_TUNE")) {          // "bn,tap_inner,halo,dma": tuning runs only
+        int v[4] = {0, -1, -1, -1};
+        sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
         if (v[0] == 32 || v[0] == 64 || v[0] == 128) bn = v[0];
         if (v[1] >= 0) d.tap_inner = v[1];
+        if (v[3] >= 0) d.dma = v[3];
     }
     if (bn == 128) launch_tile<T, 2, 2, 4, 4>(d, src, wm, bias, dst, accumulate, st);        // 128 x 128
     else if (bn == 64) launch_tile<T, 2, 2, 4, 2>(d, src, wm, bias, dst, accumulate, st);    // 128 x 64

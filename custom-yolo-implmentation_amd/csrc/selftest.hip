@@ -20,7 +20,28 @@ __global__ void k_selftest_tr16(const short* __restrict__ in, short* __restrict_
 #pragma unroll
     for (int q = 0; q < 4; ++q) { out[l * 8 + q] = r1[q]; out[l * 8 + 4 + q] = r2[q]; }
 }
+
+// LDS-DMA (buffer_load_dwordx4 ... lds): lane l's 16 bytes land at LDS base + 16*l.  Lanes with (l & 3) == 3 issue
+// an OUT-OF-RANGE voffset.  The LDS tile is pre-filled with 0xAA; the test records what those slots hold afterwards
+// (zeros = the DMA writes the range-check result, 0xAA = the write is dropped).
+__global__ void k_selftest_glds(const uint4* __restrict__ in, uint4* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint4 T[64];
+    const int l = threadIdx.x;
+    T[l] = make_uint4(0xAAAAAAAAu, 0xAAAAAAAAu, 0xAAAAAAAAu, 0xAAAAAAAAu);
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(in), 0, 128 * 16, 0x00020000);
+    const int voff = (l & 3) == 3 ? (int)0x80000000 : ((l * 2) * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)T, 16, voff, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    out[l] = T[l];
+}
 }  // namespace
+
+extern "C" int yolo_selftest_glds(const void* in128x16, void* out64x16, hipStream_t st) {
+    hipLaunchKernelGGL(k_selftest_glds, dim3(1), dim3(64), 0, st, (const uint4*)in128x16, (uint4*)out64x16);
+    return YOLO_LAUNCH_CHECK();
+}
 
 extern "C" int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st) {
     hipLaunchKernelGGL(k_selftest_tr16, dim3(1), dim3(64), 0, st, (const short*)tile_in, (short*)out);

@@ -120,6 +120,7 @@ int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, 
 
 /* ---- hardware self-tests (instruction semantics the tiled kernels assume; tests/test_gpu_selftest.py; no reference counterpart: model_blocks.py:1) */
 int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st);
+int yolo_selftest_glds(const void* in128x16, void* out64x16, hipStream_t st);
 
 #ifdef __cplusplus
 }

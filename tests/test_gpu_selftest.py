@@ -19,3 +19,23 @@ def test_ds_read_b64_tr_b16_lane_mapping():
             want[l, q] = tile[8 * g + q, i]
     print("\nlane 0:", got[0].tolist(), "lane 1:", got[1].tolist(), "lane 17:", got[17].tolist(), "lane 63:", got[63].tolist())
     assert torch.equal(got, want), "tr16 lane mapping differs from the documented one"
+
+
+def test_lds_dma_lane_layout_and_out_of_range_lanes():
+    """buffer_load_dwordx4 ... lds: lane l's 16 bytes land at LDS base + 16*l (lane-linear), and what an out-of-range
+    lane leaves in its slot is recorded here (the conv loaders rely on VGPR-destination loads returning 0; an
+    LDS-DMA loader may only rely on what this test pins)."""
+    import torch
+    from src.hipops import lib
+    src = torch.arange(128 * 4, dtype=torch.int32).view(128, 4).cuda()
+    out = torch.zeros(64, 4, dtype=torch.int32, device="cuda")
+    lib.call("yolo_selftest_glds", src.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    o = out.cpu()
+    for l in range(64):
+        if l % 4 != 3:
+            assert o[l].tolist() == src[2 * l].cpu().tolist(), (l, o[l].tolist())
+    oob = o[3::4]
+    kind = "zeros" if bool((oob == 0).all()) else "untouched" if bool((oob == -1431655766).all()) else "other"
+    print("\\n[selftest] LDS-DMA out-of-range lanes leave:", kind, oob[0].tolist())
+    assert kind in ("zeros", "untouched")

@@ -40,6 +40,9 @@ for (n, cin, h, w, cout, k, s) in shapes:
             for ti in ((0, 1) if k == 3 else (0,)):
                 os.environ["YOLO_CONV_TUNE"] = f"{bn},{ti},0"
                 res.append((timeit(fn, 0.08), bn, ti))
+        for bn in (128, 64, 32):
+            os.environ["YOLO_CONV_TUNE"] = f"{bn},0,0,1"
+            res.append((timeit(fn, 0.08), f"{bn}dma", 0))
         if k == 3 and s == 1:
             for hv in (1, 2, 3, 4):
                 os.environ["YOLO_CONV_TUNE"] = f"0,0,{hv}"
