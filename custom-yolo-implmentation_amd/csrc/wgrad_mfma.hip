@@ -264,7 +264,19 @@ WgPlan make_plan(const WgArgs& a, int k) {
         p.to = a.Cout > 32 ? 2 : 1;
         p.ti = a.Cin > 64 ? 2 : 1;
     }
-    long want_blocks = (k == 1 && p.to * p.ti == 1) ? 1024 : (k == 3 ? 256 : 512);
+    // workgroup count (= slabs x tiles): every workgroup ends by storing its tile's partial sums, so more slabs
+    // mean more partial-matrix traffic (PMC: ~4 GB per step); fewer leave CUs idle.  From tools/wg_tune.py:
+    const int cot0 = (a.Cout + 32 * p.to - 1) / (32 * p.to), cit0 = (a.Cin + 32 * p.ti - 1) / (32 * p.ti);
+    const long data_bytes = ((long)a.N * a.H * a.W * a.Cin + (long)a.N * a.OH * a.OW * a.Cout) * 2;
+    long want_blocks;
+    if (const char* e2 = getenv("YOLO_WG_BLOCKS")) {         // tuning runs only: one count for every layer
+        want_blocks = atol(e2);
+    } else if (k == 1) {
+        if (p.to * p.ti == 1) want_blocks = 2048;                                  // 32 x 32 tiles: 4 KB partials
+        else want_blocks = (cot0 * cit0 == 1 && data_bytes < (150L << 20)) ? 256 : 512;
+    } else {
+        want_blocks = p.ti == 1 ? 512 : 256;                                       // 64 x 32 x 9 vs 64 x 64 x 9 tiles
+    }
     long min_per = 2;
     if (const char* e = getenv("YOLO_WG_TUNE")) {            // "to,ti,blocks,min_per": tuning runs only
         int v[4] = {0, 0, 0, 0};

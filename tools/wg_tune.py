@@ -35,7 +35,7 @@ for (n, cin, h, w, cout, k, s) in shapes:
     tiles = [(a, b) for a in (1, 2, 3, 4) for b in (1, 2, 3, 4)] if k == 1 else [(1, 1), (1, 2), (2, 1), (2, 2)]
     tiles = [(a, b) for a, b in tiles if 32 * (a - 1) < cout and 32 * (b - 1) < cin]
     for (to, ti) in tiles:
-        for blocks in (256, 512, 1024, 2048, 4096):
+        for blocks in (64, 128, 256, 512, 1024, 2048):
             os.environ["YOLO_WG_TUNE"] = f"{to},{ti},{blocks},2"
             try:
                 us = timeit(lambda: ops.conv_wgrad(x, dy, k, s, torch.float32), 0.1)
