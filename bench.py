@@ -84,10 +84,18 @@ class KernelTimer:
                     tot += t.numel() * t.element_size()
             return float(tot)
 
+        def bn_bwd_bytes(out, dout, y, *_):          # pass 1 reads dout, y; pass 2 reads them again and writes dz
+            return 5.0 * dout.numel() * dout.element_size()
+
+        def bn_fwd_bytes(out, y, scale, shift, act, res=None, *_):
+            return (2.0 + (1.0 if res is not None else 0.0)) * y.numel() * y.element_size()
+
         self._wrap("conv_fwd", "conv_mfma(fwd+dgrad)", conv_flops, io_bytes)
         self._wrap("conv_dgrad", "conv_mfma(fwd+dgrad)", dgrad_flops, io_bytes)
         self._wrap("conv_wgrad", "wgrad_mfma", wgrad_flops, io_bytes)
-        for nm in ("bn_stats_acc", "bn_finalize_acc", "bn_act_bwd", "bn_act_fwd", "copy_channels", "dw_fwd", "dw_dgrad", "dw_wgrad",
+        self._wrap("bn_act_bwd", "bn_backward(reduce+finalize+apply)", None, bn_bwd_bytes)
+        self._wrap("bn_act_fwd", "bn_forward(normalize+act)", None, bn_fwd_bytes)
+        for nm in ("bn_stats_acc", "bn_finalize_acc", "copy_channels", "dw_fwd", "dw_dgrad", "dw_wgrad",
                    "maxpool5_fwd", "maxpool5_bwd", "upsample2x_fwd", "upsample2x_bwd", "head_pack", "head_unpack"):
             self._wrap(nm, "elementwise(bn/act/copy/pool)", None, io_bytes)
         self._wrap("attn_fwd", "attention", None, io_bytes)
@@ -195,7 +203,7 @@ def main():
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.4f} s -> {args.batch * world * args.steps / dt:.1f} img/s", file=sys.stderr, flush=True)
 
-    roofline, groups_out = None, None
+    roofline, groups_out, roofline_hbm = None, None, None
     if rank == 0 and not args.no_roofline:
         timer = KernelTimer(ops).install()
         from src.hipops import functions as F_
@@ -232,6 +240,15 @@ def main():
                         avg_launch_us=round(1e3 * g["ms"] / g["launches"], 2),
                         algorithmic_gflop_per_launch=round(g["flops"] / g["launches"] / 1e9, 3))
 
+        # the step as a whole is HBM-bound: the same measurement for the largest bandwidth-bound kernel group
+        hb = max((k for k in groups if groups[k]["flops"] == 0 and groups[k]["bytes"] > 0), key=lambda k: groups[k]["ms"])
+        gh = groups[hb]
+        ach_h = gh["bytes"] / gh["ms"] / 1e6
+        roofline_hbm = dict(bound="hbm", kernel=hb, achieved=round(ach_h, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach_h / HBM_PEAK_GBS, 4), launches=gh["launches"],
+                            avg_launch_us=round(1e3 * gh["ms"] / gh["launches"], 2),
+                            algorithmic_mb_per_launch=round(gh["bytes"] / gh["launches"] / 1e6, 2))
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.train_step import time_cpu_steps
@@ -247,7 +264,7 @@ def main():
                                         f"(fwd+DFL/QFL loss+bwd+grad sync+AdamW), COCO-80 synthetic, {args.batch} img/GPU",
                                global_batch=gb, parallelism=f"dp{world}", hip_graph=runner.graph is not None,
                                optimizer_in_graph=runner.opt_in_graph, final_loss=round(final_loss, 5)),
-                   roofline=roofline, roofline_groups=groups_out, cpu_baseline=cpu)
+                   roofline=roofline, roofline_hbm=roofline_hbm, roofline_groups=groups_out, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
