@@ -267,6 +267,7 @@ def main():
                    roofline=roofline, roofline_hbm=roofline_hbm, roofline_groups=groups_out, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                 # rank 0 may still be timing its instrumented step: leave together
         dist.destroy_process_group()
 
 
