@@ -131,8 +131,8 @@ class KernelTimer:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE config 2/3: 32)")
     ap.add_argument("--res", type=int, default=640)
     ap.add_argument("--no-graph", action="store_true")
