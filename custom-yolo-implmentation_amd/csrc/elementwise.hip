@@ -281,67 +281,80 @@ __global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, in
     }
 }
 
-// out = act(BN_batch(y)) (+ res), statistics taken from acc
+// out = act(BN_batch(y)) (+ res) with the finalize folded in: every workgroup derives scale / shift of ITS channels
+// from the statistics accumulator acc[8][2][C] (coalesced loads spread over the workgroup, then LDS); workgroup row 0
+// also publishes mean / invstd / scale / shift and updates the running statistics.  Same arithmetic as
+// k_bn_finalize_acc.
 template <typename T, int V>
-__global__ void k_bn_act_fwd_train(const T* __restrict__ y, int ldy, const float* __restrict__ acc, float count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C,
-                                   int act) {
+__global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ y, int ldy, const float* __restrict__ acc, float count,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                        float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean_out,
+                        float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
+                        const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C, int act) {
+    extern __shared__ float cf[];                            // [2][cw]: scale, shift of this workgroup's channels
     const int cv = C / V;
     const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
-    const int r = threadIdx.x / tpr;
-    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
-    if (r >= rpb || cg >= cv) return;
-    float s[V], q[V], sc[V], sh[V];
-    fold_replicas<V>(acc, C, cg * V, s, q);
+    const int cw = tpr * V;
+    for (int t = threadIdx.x; t < cw; t += TPB) {
+        const int c = blockIdx.y * cw + t;
+        float g = 0.f, sh0 = 0.f;
+        if (c < C) {
+            double s = 0.0, q = 0.0;
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        const int c = cg * V + j;
-        const float m = s[j] / count;
-        float var = q[j] / count - m * m;
-        var = var < 0.f ? 0.f : var;
-        const float is = rsqrtf(var + eps);
-        sc[j] = gamma[c] * is;
-        sh[j] = beta[c] - m * sc[j];
-        if (blockIdx.x == 0 && r == 0) {
-            mean_out[c] = m;
-            invstd_out[c] = is;
-            if (rmean) {
-                const float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
-                rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
-                rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+            for (int r = 0; r < BN_REPL; ++r) { s += acc[(long)r * 2 * C + c]; q += acc[(long)r * 2 * C + C + c]; }
+            const double m = s / count;
+            double var = q / count - m * m;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)eps));
+            g = gamma[c] * is;
+            sh0 = beta[c] - (float)m * g;
+            if (blockIdx.x == 0) {
+                mean_out[c] = (float)m;
+                invstd_out[c] = is;
+                scale_out[c] = g;
+                shift_out[c] = sh0;
+                if (rmean) {
+                    const double unb = count > 1.f ? var * (count / (count - 1.0)) : var;
+                    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+                    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+                }
             }
         }
+        cf[t] = g;
+        cf[cw + t] = sh0;
     }
+    __syncthreads();
+    const int r = threadIdx.x / tpr;
+    const int cl = threadIdx.x - r * tpr;
+    const int cg = blockIdx.y * tpr + cl;
+    if (r >= rpb || cg >= cv) return;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = cf[cl * V + j]; sh[j] = cf[cw + cl * V + j]; }
     const long step = (long)gridDim.x * rpb;
-    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
-        const long p2 = p + step;
-        const bool two = p2 < npix;
-        float a[V], b[V];
-        load_pack<T, V>(y + p * ldy + cg * V, a);
-        if (two) load_pack<T, V>(y + p2 * ldy + cg * V, b);
+    auto one = [&](long p, const pack_t<T, V>& pa, const pack_t<T, V>& pt) {
+        float a[V], t[V];
+        unpack<T, V>(pa, a);
+        if (res) unpack<T, V>(pt, t);
 #pragma unroll
-        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], act);
-        if (res) {
-            float t[V];
-            load_pack<T, V>(res + p * ldr + cg * V, t);
-#pragma unroll
-            for (int j = 0; j < V; ++j) a[j] += t[j];
-        }
+        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], act) + (res ? t[j] : 0.f);
         store_pack<T, V>(out + p * ldo + cg * V, a);
-        if (two) {
+    };
+    long p = (long)blockIdx.x * rpb + r;
+    for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {
+        pack_t<T, V> ra[RS_ROWS], rt[RS_ROWS];
 #pragma unroll
-            for (int j = 0; j < V; ++j) b[j] = act_fwd(b[j] * sc[j] + sh[j], act);
-            if (res) {
-                float t[V];
-                load_pack<T, V>(res + p2 * ldr + cg * V, t);
-#pragma unroll
-                for (int j = 0; j < V; ++j) b[j] += t[j];
-            }
-            store_pack<T, V>(out + p2 * ldo + cg * V, b);
+        for (int k = 0; k < RS_ROWS; ++k) {
+            ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
+            if (res) rt[k] = load_raw<T, V>(res + (p + k * step) * ldr + cg * V);
         }
+#pragma unroll
+        for (int k = 0; k < RS_ROWS; ++k) one(p + k * step, ra[k], rt[k]);
+    }
+    for (; p < npix; p += step) {
+        pack_t<T, V> pa = load_raw<T, V>(y + p * ldy + cg * V), pt;
+        if (res) pt = load_raw<T, V>(res + p * ldr + cg * V);
+        one(p, pa, pt);
     }
 }
 
@@ -928,14 +941,15 @@ int yolo_bn_finalize_acc(const float* acc, long count, int C, const float* gamma
 
 int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                          const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype,
-                          hipStream_t st) {
+                          float* scale, float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C,
+                          int act, int dtype, hipStream_t st) {
     YOLO_DISPATCH_T(dtype, {
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(out, ldout, C) && (!res || vec_ok<T>(res, ldres, C));
         PICK_V(T, ok, {
-            hipLaunchKernelGGL((k_bn_act_fwd_train<T, V>), rs_grid(npix, C / V), dim3(TPB), 0, st, (const T*)y, ldy, acc,
-                               (float)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                               (const T*)res, ldres, (T*)out, ldout, npix, C, act);
+            const int cv = C / V, tpr = cv < TPB ? cv : TPB;
+            hipLaunchKernelGGL((k_bn_act_fwd_train<T, V>), rs_grid(npix, cv), dim3(TPB), 2 * tpr * V * sizeof(float), st,
+                               (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act);
         });
     });
     return YOLO_LAUNCH_CHECK();

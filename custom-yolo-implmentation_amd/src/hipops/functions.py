@@ -31,6 +31,7 @@ def _f32(t):
 
 
 _SIDE = {}
+FOLD_BN_FINALIZE = True     # BN scale/shift are derived in the prologue of the activation kernel (no finalize launch)
 OVERLAP_WGRAD = True        # run a conv's weight gradient on a side stream, concurrently with its data gradient
 
 
@@ -111,15 +112,19 @@ class ConvBnAct(torch.autograd.Function):
             res = _as_nhwc(res, T)
         if training:
             rm32, rv32 = _f32(rm), _f32(rv)
-            count = y.shape[0] * y.shape[2] * y.shape[3]
-            mean, invstd, scale, shift = ops.bn_finalize_acc(acc_f, count, g32, b32, rm32, rv32, momentum, eps)
+            if FOLD_BN_FINALIZE:
+                out, mean, invstd, scale, shift = ops.bn_act_fwd_train(y, acc_f, g32, b32, rm32, rv32, momentum, eps, act, res, out)
+            else:
+                count = y.shape[0] * y.shape[2] * y.shape[3]
+                mean, invstd, scale, shift = ops.bn_finalize_acc(acc_f, count, g32, b32, rm32, rv32, momentum, eps)
+                out = ops.bn_act_fwd(y, scale, shift, act, res, out)
             if rm32 is not rm:
                 rm.copy_(rm32)
                 rv.copy_(rv32)
         else:
             mean = invstd = None
             scale, shift = ops.bn_eval_coeffs(g32, b32, _f32(rm), _f32(rv), eps)
-        out = ops.bn_act_fwd(y, scale, shift, act, res, out)
+            out = ops.bn_act_fwd(y, scale, shift, act, res, out)
         saved = (scale, shift, mean, invstd, g32)
         ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype, stem)
         ctx.save_for_backward(x, weight, y, *saved)

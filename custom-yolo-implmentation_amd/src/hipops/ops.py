@@ -221,16 +221,18 @@ def bn_finalize_acc(acc, count, gamma, beta, running_mean, running_var, momentum
     return mean, invstd, scale, shift
 
 
-def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, eps, act, res=None):
-    """act(BN(y)) (+res) with batch statistics read from acc; updates running stats; -> (out, mean, invstd)."""
+def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, eps, act, res=None, out=None):
+    """act(BN(y)) (+res) with the batch statistics read from acc (finalize folded into the kernel's prologue);
+    updates running stats; -> (out, mean, invstd, scale, shift)."""
     n, c, h, w, ld = geom(y)
-    out = new_nhwc(n, c, h, w, y.dtype, y.device)
-    mean, invstd = _f32(c, y.device), _f32(c, y.device)
+    out = _dest(out, n, c, h, w, y.dtype, y.device)
+    coef = _f32(4 * c, y.device)
+    mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
     ldr = geom(res)[4] if res is not None else 0
     lib.call("yolo_bn_act_fwd_train", _p(y), ld, _p(acc), n * h * w, _p(gamma), _p(beta), _p(running_mean),
-             _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(res), ldr, _p(out), c, n * h * w, c,
-             int(act), dt(y), _stream(y))
-    return out, mean, invstd
+             _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), _p(res), ldr, _p(out),
+             geom(out)[4], n * h * w, c, int(act), dt(y), _stream(y))
+    return out, mean, invstd, scale, shift
 
 
 def bn_act_bwd_train(dout, y, gamma, beta, mean, invstd, act, acc):

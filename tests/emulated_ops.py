@@ -91,7 +91,7 @@ def bn_finalize_acc(acc, count, gamma, beta, running_mean, running_var, momentum
     return mean, invstd, scale, beta - mean * scale
 
 
-def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, eps, act, res=None):
+def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, eps, act, res=None, out=None):
     c = y.shape[1]
     cnt = y.numel() // c
     s = acc.view(real.BN_REPL, 2, c).sum(0)
@@ -101,7 +101,8 @@ def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, e
     running_mean.mul_(1 - momentum).add_(momentum * mean)
     running_var.mul_(1 - momentum).add_(momentum * var * (cnt / max(cnt - 1, 1)))
     scale = gamma * invstd
-    return bn_act_fwd(y, scale, beta - mean * scale, act, res), mean, invstd
+    shift = beta - mean * scale
+    return bn_act_fwd(y, scale, shift, act, res, out), mean, invstd, scale, shift
 
 
 def bn_act_bwd_train(dout, y, gamma, beta, mean, invstd, act, acc):

@@ -214,8 +214,10 @@ def test_bn_accumulator_path_with_conv_epilogue_stats(dtype, cin, cout, h, w, k,
     for a_, b_, nm in zip(fin, fin_r, ("mean", "invstd", "scale", "shift")):
         check(a_, b_, torch.float32, "finalize_acc " + nm, mult=100.0 if dtype != torch.float32 else 4.0, scale=max(1.0, float(b_.abs().max())))
     res = nhwc(rnd(*y_ref.shape, seed=66).to(dtype))
-    out, mean, invstd = o.bn_act_fwd_train(y, acc_f, gamma.to(DEV), beta.to(DEV), rm_g, rv_g, 0.03, 1e-3, act, dev(res))
-    out_r, mean_r, invstd_r = emu.bn_act_fwd_train(y_ref, ref_f, gamma, beta, rm, rv, 0.03, 1e-3, act, res)
+    out, mean, invstd, scale, shift = o.bn_act_fwd_train(y, acc_f, gamma.to(DEV), beta.to(DEV), rm_g, rv_g, 0.03, 1e-3, act, dev(res))
+    out_r, mean_r, invstd_r, scale_r, shift_r = emu.bn_act_fwd_train(y_ref, ref_f, gamma, beta, rm, rv, 0.03, 1e-3, act, res)
+    check(scale, scale_r, torch.float32, "scale", mult=100.0 if dtype != torch.float32 else 4.0, scale=max(1.0, float(scale_r.abs().max())))
+    check(shift, shift_r, torch.float32, "shift", mult=100.0 if dtype != torch.float32 else 4.0, scale=max(1.0, float(shift_r.abs().max())))
     check(mean, mean_r, torch.float32, "mean", mult=50.0 if dtype != torch.float32 else 4.0, scale=float(y_ref.float().abs().max()))
     check(invstd, invstd_r, torch.float32, "invstd", mult=100.0 if dtype != torch.float32 else 4.0)
     check(out, out_r, dtype, "bn_act_fwd_train", mult=2.0)
