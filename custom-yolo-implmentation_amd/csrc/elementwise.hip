@@ -185,7 +185,7 @@ __device__ __forceinline__ void fold_replicas(const float* __restrict__ acc, int
 
 // MODE 0: acc += (sum y, sum y^2).  MODE 1: acc += (sum dz, sum dz*yhat) with z = (y-mean)*invstd*gamma + beta
 template <typename T, int V, int MODE>
-__global__ void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               const float* __restrict__ mean, const float* __restrict__ invstd,
                               long npix, int C, int act, float* __restrict__ acc) {
@@ -200,14 +200,10 @@ __global__ void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restr
 #pragma unroll
     for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
     if (active) {
-        float sc[V], sh[V], mu[V], is[V];
-        if (MODE == 1) {
+        float sc[V], sh[V];
+        if (MODE == 1) {                                    // MODE 1: gamma / beta carry the forward's scale / shift
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const int c = cg * V + j;
-                mu[j] = mean[c]; is[j] = invstd[c];
-                sc[j] = gamma[c] * is[j]; sh[j] = beta[c] - mu[j] * sc[j];
-            }
+            for (int j = 0; j < V; ++j) { sc[j] = gamma[cg * V + j]; sh[j] = beta[cg * V + j]; }
         }
         const long step = (long)gridDim.x * rpb;
         auto one = [&](const pack_t<T, V>& pa, const pack_t<T, V>& pd) {
@@ -220,7 +216,7 @@ __global__ void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restr
                 else {
                     float dz = d[j] * act_grad(a[j] * sc[j] + sh[j], act);
                     s[j] += dz;
-                    q[j] += dz * ((a[j] - mu[j]) * is[j]);
+                    q[j] += dz * a[j];            // raw; the apply kernel centres it
                 }
             }
         };
@@ -358,54 +354,69 @@ __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ 
     }
 }
 
-// dy = A*dz + B*y + D with the constants derived from acc = (sum dz, sum dz*yhat); block (0,y) writes dgamma/dbeta
+// dy = A*dz + B*y + D with the backward finalize folded in: acc[8][2][C] holds (sum dz, sum dz*y) of the reduction
+// kernel (float atomics into 8 replicas); every workgroup folds the replicas of ITS channels, centres the second
+// sum (sum dz*yhat = invstd*(sum dz*y - mean*sum dz)) and derives the five constants into LDS; workgroup row 0
+// also writes dgamma / dbeta.  Same arithmetic as k_bn_bwd_finalize (double).
 template <typename T, int V>
-__global__ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                         const float* __restrict__ acc, float count, float* __restrict__ dgamma,
-                                         float* __restrict__ dbeta, T* __restrict__ dy, int lddy, long npix, int C,
-                                         int act) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 8)))
+void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
+                              const float* __restrict__ scale, const float* __restrict__ shift,
+                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                              const float* __restrict__ invstd, const float* __restrict__ acc, float count,
+                              float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ dy, int lddy,
+                              long npix, int C, int act) {
+    extern __shared__ float cf[];                            // [5][cw]: scale, shift, A, B, D
     const int cv = C / V;
     const int tpr = cv < TPB ? cv : TPB, rpb = TPB / tpr;
+    const int cw = tpr * V;
+    for (int t = threadIdx.x; t < cw; t += TPB) {
+        const int c = blockIdx.y * cw + t;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        if (c < C) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int r = 0; r < BN_REPL; ++r) { s += acc[(long)r * 2 * C + c]; q += acc[(long)r * 2 * C + C + c]; }
+            const double is = invstd[c], mu = mean[c];
+            q = is * (q - mu * s);                           // sum(dz*yhat)
+            const double k0 = (double)gamma[c] * is, c1 = s / count, c2 = q / count;
+            v0 = scale[c]; v1 = shift[c];
+            v2 = (float)k0;
+            v3 = (float)(-k0 * c2 * is);
+            v4 = (float)(-k0 * c1 + k0 * c2 * mu * is);
+            if (blockIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)q; }
+        }
+        cf[t] = v0; cf[cw + t] = v1; cf[2 * cw + t] = v2; cf[3 * cw + t] = v3; cf[4 * cw + t] = v4;
+    }
+    __syncthreads();
     const int r = threadIdx.x / tpr;
-    const int cg = blockIdx.y * tpr + (threadIdx.x - r * tpr);
+    const int cl = threadIdx.x - r * tpr;
+    const int cg = blockIdx.y * tpr + cl;
     if (r >= rpb || cg >= cv) return;
-    float s[V], q[V], sc[V], sh[V], cA[V], cB[V], cD[V];
-    fold_replicas<V>(acc, C, cg * V, s, q);
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-        const int c = cg * V + j;
-        const float is = invstd[c], mu = mean[c], k0 = gamma[c] * is;
-        sc[j] = k0;
-        sh[j] = beta[c] - mu * k0;
-        const float c1 = s[j] / count, c2 = q[j] / count;
-        cA[j] = k0;
-        cB[j] = -k0 * c2 * is;
-        cD[j] = -k0 * c1 + k0 * c2 * mu * is;
-        if (blockIdx.x == 0 && r == 0) { dbeta[c] = s[j]; dgamma[c] = q[j]; }
-    }
+    const float* my = cf + cl * V;
     const long step = (long)gridDim.x * rpb;
-    for (long p = (long)blockIdx.x * rpb + r; p < npix; p += 2 * step) {
-        const long p2 = p + step;
-        const bool two = p2 < npix;
-        float a[V], d[V], a2[V], d2[V];
-        load_pack<T, V>(y + p * ldy + cg * V, a);
-        load_pack<T, V>(dout + p * ldd + cg * V, d);
-        if (two) {
-            load_pack<T, V>(y + p2 * ldy + cg * V, a2);
-            load_pack<T, V>(dout + p2 * ldd + cg * V, d2);
-        }
+    auto one = [&](long p, const pack_t<T, V>& pa, const pack_t<T, V>& pd) {
+        float a[V], d[V];
+        unpack<T, V>(pa, a);
+        unpack<T, V>(pd, d);
 #pragma unroll
-        for (int j = 0; j < V; ++j) d[j] = cA[j] * (d[j] * act_grad(a[j] * sc[j] + sh[j], act)) + cB[j] * a[j] + cD[j];
+        for (int j = 0; j < V; ++j)
+            d[j] = my[2 * cw + j] * (d[j] * act_grad(a[j] * my[j] + my[cw + j], act)) + my[3 * cw + j] * a[j] + my[4 * cw + j];
         store_pack<T, V>(dy + p * lddy + cg * V, d);
-        if (two) {
+    };
+    long p = (long)blockIdx.x * rpb + r;
+    for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {
+        pack_t<T, V> ra[RS_ROWS], rd[RS_ROWS];
 #pragma unroll
-            for (int j = 0; j < V; ++j)
-                d2[j] = cA[j] * (d2[j] * act_grad(a2[j] * sc[j] + sh[j], act)) + cB[j] * a2[j] + cD[j];
-            store_pack<T, V>(dy + p2 * lddy + cg * V, d2);
+        for (int k = 0; k < RS_ROWS; ++k) {
+            ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
+            rd[k] = load_raw<T, V>(dout + (p + k * step) * ldd + cg * V);
         }
+#pragma unroll
+        for (int k = 0; k < RS_ROWS; ++k) one(p + k * step, ra[k], rd[k]);
     }
+    for (; p < npix; p += step)
+        one(p, load_raw<T, V>(y + p * ldy + cg * V), load_raw<T, V>(dout + p * ldd + cg * V));
 }
 
 // Finalize kernels run as (32 channels x 32 parts) 1024-thread workgroups: part j sums partial blocks
@@ -955,21 +966,23 @@ int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, 
     return YOLO_LAUNCH_CHECK();
 }
 
-int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta,
-                           const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* acc,
-                           hipStream_t st) {
-    return launch_acc(1, y, ldy, dout, ldd, gamma, beta, mean, invstd, npix, C, act, dtype, acc, st);
+// backward pass 1 with atomics: acc[8][2][C] (zeroed by the caller) += (sum dz, sum dz*y), dz = dout*act'(y*scale+shift)
+int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift,
+                           long npix, int C, int act, int dtype, float* acc, hipStream_t st) {
+    return launch_acc(1, y, ldy, dout, ldd, scale, shift, nullptr, nullptr, npix, C, act, dtype, acc, st);
 }
 
-int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta,
-                                const float* mean, const float* invstd, const float* acc, long count, float* dgamma,
-                                float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st) {
+int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift,
+                                const float* gamma, const float* mean, const float* invstd, const float* acc, long count,
+                                float* dgamma, float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype,
+                                hipStream_t st) {
     YOLO_DISPATCH_T(dtype, {
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(dout, ldd, C) && vec_ok<T>(dy, lddy, C);
         PICK_V(T, ok, {
-            hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V>), rs_grid(npix, C / V), dim3(TPB), 0, st, (const T*)dout, ldd,
-                               (const T*)y, ldy, gamma, beta, mean, invstd, acc, (float)count, dgamma, dbeta, (T*)dy, lddy,
-                               npix, C, act);
+            const int cv = C / V, tpr = cv < TPB ? cv : TPB;
+            hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V>), rs_grid(npix, cv), dim3(TPB), 5 * tpr * V * sizeof(float), st,
+                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
+                               dgamma, dbeta, (T*)dy, lddy, npix, C, act);
         });
     });
     return YOLO_LAUNCH_CHECK();

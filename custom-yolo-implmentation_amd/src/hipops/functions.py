@@ -74,7 +74,7 @@ class BnArena:
 
     @staticmethod
     def elems_for(channels):
-        return sum(ops.BN_REPL * 2 * c for c in channels)
+        return 2 * sum(ops.BN_REPL * 2 * c for c in channels)      # forward statistics + backward sums per layer
 
 
 class ConvBnAct(torch.autograd.Function):
@@ -110,8 +110,11 @@ class ConvBnAct(torch.autograd.Function):
         rm, rv = bufs
         if res is not None:
             res = _as_nhwc(res, T)
+        acc_b = None
         if training:
             rm32, rv32 = _f32(rm), _f32(rv)
+            if FOLD_BN_FINALIZE and BnArena.current is not None:
+                acc_b = BnArena.current.take(cout)          # zeroed with the forward statistics; used by the backward
             if FOLD_BN_FINALIZE:
                 out, mean, invstd, scale, shift = ops.bn_act_fwd_train(y, acc_f, g32, b32, rm32, rv32, momentum, eps, act, res, out)
             else:
@@ -126,6 +129,7 @@ class ConvBnAct(torch.autograd.Function):
             scale, shift = ops.bn_eval_coeffs(g32, b32, _f32(rm), _f32(rv), eps)
             out = ops.bn_act_fwd(y, scale, shift, act, res, out)
         saved = (scale, shift, mean, invstd, g32)
+        ctx.acc_b = acc_b       # a slice of the arena other layers write to: kept off save_for_backward's version check
         ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype, stem)
         ctx.save_for_backward(x, weight, y, *saved)
         return _fresh(out)
@@ -137,7 +141,10 @@ class ConvBnAct(torch.autograd.Function):
         T = y.dtype
         dout = _as_nhwc(dout, T)
         scale, shift, mean, invstd, g32 = ctx.saved_tensors[3:]
-        if training:
+        acc_b = ctx.acc_b
+        if training and acc_b is not None:
+            dy, dgamma, dbeta = ops.bn_act_bwd_train(dout, y, scale, shift, mean, invstd, g32, act, acc_b)
+        elif training:
             dy, dgamma, dbeta = ops.bn_act_bwd(dout, y, scale, shift, mean, invstd, g32, act)
         else:
             dy, dgamma, dbeta = ops.bn_act_bwd_eval(dout, y, scale, shift, act), None, None

@@ -235,18 +235,19 @@ def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, e
     return out, mean, invstd, scale, shift
 
 
-def bn_act_bwd_train(dout, y, gamma, beta, mean, invstd, act, acc):
-    """Backward of act(BN_batch(y)): acc (zeroed) collects sum(dz), sum(dz*yhat); -> (dy, dgamma, dbeta)."""
+def bn_act_bwd_train(dout, y, scale, shift, mean, invstd, gamma, act, acc):
+    """Backward of act(BN_batch(y)) in two launches: the reduction adds (sum dz, sum dz*y) into acc (fp32 [8][2][C],
+    zeroed by the caller) with float atomics, the apply kernel folds the finalize into its prologue.
+    -> (dy, dgamma, dbeta)."""
     n, c, h, w, ldy = geom(y)
     ldd = geom(dout)[4]
     npix = n * h * w
     st = _stream(y)
-    lib.call("yolo_bn_bwd_reduce_acc", _p(dout), ldd, _p(y), ldy, _p(gamma), _p(beta), _p(mean), _p(invstd), npix, c,
-             int(act), dt(y), _p(acc), st)
+    lib.call("yolo_bn_bwd_reduce_acc", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), npix, c, int(act), dt(y), _p(acc), st)
     dgamma, dbeta = _f32(c, y.device), _f32(c, y.device)
     dy = new_nhwc(n, c, h, w, y.dtype, y.device)
-    lib.call("yolo_bn_act_bwd_apply_train", _p(dout), ldd, _p(y), ldy, _p(gamma), _p(beta), _p(mean), _p(invstd), _p(acc),
-             npix, _p(dgamma), _p(dbeta), _p(dy), c, npix, c, int(act), dt(y), st)
+    lib.call("yolo_bn_act_bwd_apply_train", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), _p(gamma), _p(mean), _p(invstd),
+             _p(acc), npix, _p(dgamma), _p(dbeta), _p(dy), c, npix, c, int(act), dt(y), st)
     return dy, dgamma, dbeta
 
 

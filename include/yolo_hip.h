@@ -92,8 +92,8 @@ int yolo_bn_acc_elems(int C);
 int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int dtype, float* acc, hipStream_t st);
 int yolo_bn_finalize_acc(const float* acc, long count, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
 int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype, hipStream_t st);
-int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta, const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* acc, hipStream_t st);
-int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* gamma, const float* beta, const float* mean, const float* invstd, const float* acc, long count, float* dgamma, float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
+int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, long npix, int C, int act, int dtype, float* acc, hipStream_t st);
+int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* gamma, const float* mean, const float* invstd, const float* acc, long count, float* dgamma, float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
 
 /* ---- SPPF max pool (model_blocks.py:150-156) and nearest x2 upsample (neck.py:31,41-42) */
 int yolo_maxpool5_fwd(const void* x, int ldx, void* out, int ldo, uint8_t* idx, int N, int H, int W, int C, int dtype, hipStream_t st);

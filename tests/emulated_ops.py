@@ -105,9 +105,8 @@ def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, e
     return bn_act_fwd(y, scale, shift, act, res, out), mean, invstd, scale, shift
 
 
-def bn_act_bwd_train(dout, y, gamma, beta, mean, invstd, act, acc):
-    scale = gamma * invstd
-    return bn_act_bwd(dout, y, scale, beta - mean * scale, mean, invstd, gamma, act)
+def bn_act_bwd_train(dout, y, scale, shift, mean, invstd, gamma, act, acc):
+    return bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act)
 
 
 def conv_dgrad(dy, wb, cin, h, w, k, stride):

@@ -223,8 +223,8 @@ def test_bn_accumulator_path_with_conv_epilogue_stats(dtype, cin, cout, h, w, k,
     check(out, out_r, dtype, "bn_act_fwd_train", mult=2.0)
     check(rm_g, rm, torch.float32, "running_mean", mult=50.0), check(rv_g, rv, torch.float32, "running_var", mult=100.0)
     dout = nhwc(rnd(*y_ref.shape, seed=67).to(dtype))
-    dy, dg, db = o.bn_act_bwd_train(dev(dout), y, gamma.to(DEV), beta.to(DEV), mean, invstd, act, acc_b)
-    dy_r, dg_r, db_r = emu.bn_act_bwd_train(dout, y.cpu(), gamma, beta, mean.cpu(), invstd.cpu(), act, ref_b)
+    dy, dg, db = o.bn_act_bwd_train(dev(dout), y, scale, shift, mean, invstd, gamma.to(DEV), act, acc_b)
+    dy_r, dg_r, db_r = emu.bn_act_bwd_train(dout, y.cpu(), scale.cpu(), shift.cpu(), mean.cpu(), invstd.cpu(), gamma, act, ref_b)
     check(dy, dy_r, dtype, "bn bwd dy", mult=2.0)
     check(dg, dg_r, torch.float32, "dgamma", mult=20.0), check(db, db_r, torch.float32, "dbeta", mult=20.0)
 
