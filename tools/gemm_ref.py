@@ -18,7 +18,9 @@ def timeit(fn, secs=0.6):
     e1.record(); torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / 20
 
-for (M, K, N) in [(204800, 1152, 128), (819200, 576, 64), (819200, 96, 128), (3276800, 32, 32), (51200, 2304, 256), (12800, 4608, 512), (204800, 512, 128)]:
+for (M, K, N) in [(204800, 1152, 128), (819200, 576, 64), (819200, 96, 128), (3276800, 32, 32), (51200, 2304, 256), (12800, 4608, 512), (204800, 512, 128),
+                  (12800, 1024, 512), (12800, 768, 512), (12800, 512, 256), (12800, 256, 256), (12800, 512, 1024), (51200, 384, 256),
+                  (51200, 256, 256), (51200, 768, 256)]:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     b = torch.randn(K, N, device="cuda", dtype=torch.bfloat16)
     us = timeit(lambda: torch.matmul(a, b))
