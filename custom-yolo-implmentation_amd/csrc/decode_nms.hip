@@ -253,6 +253,179 @@ __global__ __launch_bounds__(64) void k_scan(const float* __restrict__ rows, con
     if (lane == 0) out_count[img] = kept;
 }
 
+// ---- validation path: reference src/training/train_model.py:14-142 (decode_predictions) and
+// src/training/metrics.py:68-157 (DetectionMetrics.update) -------------------------------------------------------
+// k_val_candidates : per anchor sigmoid of every class logit rounded in T (the reference applies .sigmoid() to the T
+//                    tensor), first maximum, `>= conf` compared in T; order-preserving compaction
+// k_val_rank       : only for images with more survivors than top_k: descending score, lower anchor first on ties
+//                    (torch.topk leaves the order of equal scores unspecified)
+// k_val_gather     : the kept rows [cx, cy, w, h, cls, score] per image
+// k_val_match      : one wave per image walks the predictions in order; each takes the free same-class target of
+//                    highest IoU (strict >, so the first index wins a tie and IoU 0 never matches), TP when that IoU
+//                    (as double) >= threshold; int64 counters [total_pred, total_gt, tp, fp, fn, class_tp[nc],
+//                    class_fp[nc], class_fn[nc], class_gt[nc]] updated with atomics
+template <typename T>
+__global__ __launch_bounds__(256) void k_val_candidates(const T* __restrict__ y, int nc, int M, float conf,
+                                                        float* __restrict__ rows /*[N][M][6]*/, int* __restrict__ count) {
+    __shared__ int lds4[4];
+    const int img = blockIdx.x;
+    const T* yi = y + (long)img * (4 + nc) * M;
+    float* out = rows + (long)img * M * 6;
+    conf = rt<T>(conf);
+    int base = 0;
+    for (int m0 = 0; m0 < M; m0 += 256) {
+        const int m = m0 + threadIdx.x;
+        int keep = 0, bestc = 0;
+        float best = -INFINITY;
+        if (m < M) {
+            for (int c = 0; c < nc; ++c) {
+                const float v = to_f<T>(yi[(long)(4 + c) * M + m]);
+                const float sg = rt<T>(1.f / (1.f + expf(-v)));
+                if (sg > best) { best = sg; bestc = c; }
+            }
+            keep = best >= conf ? 1 : 0;
+        }
+        int total;
+        const int pos = base + block_excl_scan(keep, lds4, total);
+        if (keep) {
+            float* r = out + (long)pos * 6;
+            r[0] = to_f<T>(yi[m]); r[1] = to_f<T>(yi[(long)M + m]); r[2] = to_f<T>(yi[2L * M + m]);
+            r[3] = to_f<T>(yi[3L * M + m]); r[4] = (float)bestc; r[5] = best;
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) count[img] = base;
+}
+
+__global__ __launch_bounds__(256) void k_val_rank(const float* __restrict__ rows, const int* __restrict__ count, int M,
+                                                  int top_k, int* __restrict__ sel /*[N][top_k]*/) {
+    __shared__ float sc[256];
+    const int img = blockIdx.y;
+    const int n = count[img];
+    if (n <= top_k || blockIdx.x * 256 >= n) return;
+    const float* r = rows + (long)img * M * 6;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float mine = i < n ? r[(long)i * 6 + 5] : 0.f;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        const int j = j0 + threadIdx.x;
+        sc[threadIdx.x] = j < n ? r[(long)j * 6 + 5] : -INFINITY;
+        __syncthreads();
+        const int lim = n - j0 < 256 ? n - j0 : 256;
+        for (int k = 0; k < lim; ++k) {
+            const float o = sc[k];
+            rank += (o > mine) || (o == mine && j0 + k < i);
+        }
+    }
+    if (i < n && rank < top_k) sel[(long)img * top_k + rank] = i;
+}
+
+__global__ __launch_bounds__(64) void k_val_gather(const float* __restrict__ rows, const int* __restrict__ count, int M,
+                                                   int top_k, const int* __restrict__ sel, float* __restrict__ out,
+                                                   int* __restrict__ out_count) {
+    const int img = blockIdx.x;
+    const int n = count[img];
+    const int k = n < top_k ? n : top_k;
+    const float* r = rows + (long)img * M * 6;
+    float* o = out + (long)img * top_k * 6;
+    for (int e = threadIdx.x; e < top_k * 6; e += 64) {
+        const int row = e / 6, col = e - row * 6;
+        float v = 0.f;
+        if (row < k) v = r[(long)(n > top_k ? sel[(long)img * top_k + row] : row) * 6 + col];
+        o[e] = v;
+    }
+    if (threadIdx.x == 0) out_count[img] = k;
+}
+
+constexpr int VAL_MAX_T = 16;       // targets per lane: images with up to 1024 ground-truth boxes
+
+struct Corners { float x1, y1, x2, y2; };
+__device__ __forceinline__ Corners corners_of(const float* b) {     // metrics.py:19-24, each op rounded in fp32
+    const float hw = b[2] / 2.f, hh = b[3] / 2.f;
+    return {b[0] - hw, b[1] - hh, b[0] + hw, b[1] + hh};
+}
+__device__ __forceinline__ float iou_xywh(const Corners& a, const Corners& b) {     // metrics.py:29-41
+    float w = fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), h = fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1);
+    w = w < 0.f ? 0.f : w;
+    h = h < 0.f ? 0.f : h;
+    const float inter = w * h;
+    const float a1 = (a.x2 - a.x1) * (a.y2 - a.y1), a2 = (b.x2 - b.x1) * (b.y2 - b.y1);
+    return inter / ((a1 + a2) - inter + 1e-6f);
+}
+__device__ __forceinline__ void bump(long long* c, long long v) {
+    if (v) atomicAdd(reinterpret_cast<unsigned long long*>(c), (unsigned long long)v);
+}
+
+__global__ __launch_bounds__(64) void k_val_match(const float* __restrict__ pred /*[N][top_k][6]*/,
+                                                  const int* __restrict__ count, int top_k,
+                                                  const float* __restrict__ gt /*[total][5]*/,
+                                                  const int* __restrict__ gt_off, double thr, int nc, int skip_empty_gt,
+                                                  long long* __restrict__ ctr, int* __restrict__ status) {
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int n = count[img];
+    const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
+    if ((n == 0 && m == 0) || (m == 0 && skip_empty_gt)) return;
+    if (m > 64 * VAL_MAX_T) { if (lane == 0) *status = 1; return; }
+    long long *c_tp = ctr + 5, *c_fp = c_tp + nc, *c_fn = c_fp + nc, *c_gt = c_fn + nc;
+    const float* P = pred + (long)img * top_k * 6;
+    const float* G = gt + (long)g0 * 5;
+    if (n == 0) {                                               // :91-98 (totals are not advanced on this path)
+        for (int j = lane; j < m; j += 64) {
+            const long long c = (long long)G[j * 5 + 4];
+            if (c >= 0 && c < nc) { bump(c_fn + c, 1); bump(c_gt + c, 1); }
+        }
+        if (lane == 0) bump(ctr + 4, m);
+        return;
+    }
+    if (m == 0) {                                               // :100-106
+        for (int i = lane; i < n; i += 64) {
+            const long long c = (long long)P[i * 6 + 4];
+            if (c >= 0 && c < nc) bump(c_fp + c, 1);
+        }
+        if (lane == 0) bump(ctr + 3, n);
+        return;
+    }
+    unsigned taken = 0;                                         // bit t: target lane + 64 t is matched
+    int tp = 0;
+    for (int i = 0; i < n; ++i) {
+        const Corners pb = corners_of(P + i * 6);
+        const long long pc = (long long)P[i * 6 + 4];
+        float best = 0.f;
+        int bj = 0x7fffffff;
+        for (int t = 0, j = lane; j < m; ++t, j += 64) {
+            if ((taken >> t) & 1u) continue;
+            if ((long long)G[j * 5 + 4] != pc) continue;
+            const float v = iou_xywh(pb, corners_of(G + j * 5));
+            if (v > best) { best = v; bj = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                      // max IoU, lowest target index on ties
+            const float ob = __shfl_xor(best, o, 64);
+            const int oj = __shfl_xor(bj, o, 64);
+            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        const bool hit = bj != 0x7fffffff && (double)best >= thr;
+        if (hit && (bj & 63) == lane) taken |= 1u << (bj >> 6);
+        if (lane == 0) {
+            tp += hit;
+            if (pc >= 0 && pc < nc) bump((hit ? c_tp : c_fp) + pc, 1);
+        }
+    }
+    int unmatched = 0;
+    for (int t = 0, j = lane; j < m; ++t, j += 64) {            // :148-156
+        const long long c = (long long)G[j * 5 + 4];
+        const bool free_ = !((taken >> t) & 1u);
+        unmatched += free_;
+        if (c >= 0 && c < nc) { bump(c_gt + c, 1); if (free_) bump(c_fn + c, 1); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) unmatched += __shfl_xor(unmatched, o, 64);
+    if (lane == 0) {
+        bump(ctr + 0, n); bump(ctr + 1, m); bump(ctr + 2, tp); bump(ctr + 3, n - tp); bump(ctr + 4, unmatched);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -324,6 +497,41 @@ int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, 
     }
     rc = hip_status(hipMemcpyAsync(status, overflow, 4, hipMemcpyDeviceToDevice, st));
     if (rc) return rc;
+    return YOLO_LAUNCH_CHECK();
+}
+
+// ---- validation (train_model.py:14-142, metrics.py:68-157) ----
+size_t yolo_val_workspace_bytes(int N, int M, int top_k) {
+    return (size_t)N * M * 6 * 4 + (size_t)N * top_k * 4 + (size_t)N * 4 + 64;
+}
+
+// y: decoded head output (N, 4+nc, M) of dtype (yolo_head_decode).  out: fp32 [N][top_k][6] rows
+// (cx, cy, w, h, cls, score), zero padded; out_count: int32 [N].
+int yolo_val_select(const void* y, int dtype, int N, int nc, int M, float conf, int top_k, float* out, int* out_count,
+                    void* workspace, hipStream_t st) {
+    if (N < 1 || M < 1 || top_k < 1 || nc < 1) return YOLO_ERR_ARG;
+    char* ws = (char*)workspace;
+    float* rows = (float*)ws;
+    ws += (size_t)N * M * 6 * 4;
+    int* sel = (int*)ws;
+    ws += (size_t)N * top_k * 4;
+    int* count = (int*)ws;
+    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_val_candidates<T>), dim3(N), dim3(256), 0, st, (const T*)y, nc, M, conf, rows,
+                                              count));
+    hipLaunchKernelGGL(k_val_rank, dim3(ceil_div(M, 256), N), dim3(256), 0, st, rows, count, M, top_k, sel);
+    hipLaunchKernelGGL(k_val_gather, dim3(N), dim3(64), 0, st, rows, count, M, top_k, sel, out, out_count);
+    return YOLO_LAUNCH_CHECK();
+}
+
+// pred: fp32 [N][top_k][6] (first 5 columns used), count: int32 [N]; gt: fp32 [total][5] (cx, cy, w, h, cls) with
+// image i owning rows gt_off[i] .. gt_off[i+1]; counters: int64 [5 + 4 nc], accumulated (zero them to reset);
+// skip_empty_gt: ignore images without targets (the reference's validation loop does, train_model.py:326-328);
+// status: int32[1] set to 1 if an image has more than 1024 targets (counters then incomplete).
+int yolo_val_match(const float* pred, const int* count, int N, int top_k, const float* gt, const int* gt_off, double iou_thr,
+                   int nc, int skip_empty_gt, long long* counters, int* status, hipStream_t st) {
+    if (N < 1 || top_k < 1 || nc < 1) return YOLO_ERR_ARG;
+    hipLaunchKernelGGL(k_val_match, dim3(N), dim3(64), 0, st, pred, count, top_k, gt, gt_off, iou_thr, nc, skip_empty_gt,
+                       counters, status);
     return YOLO_LAUNCH_CHECK();
 }
 

@@ -16,7 +16,7 @@ F32, BF16, F16 = 0, 1, 2
 ACT_IDENTITY, ACT_SILU = 0, 1
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
-       "hipStream_t": ctypes.c_void_p}
+       "double": ctypes.c_double, "hipStream_t": ctypes.c_void_p}
 _PROTO = re.compile(r"^(int|long|size_t)\s+(yolo_\w+)\s*\(([^)]*)\)\s*;", re.M)
 
 

@@ -510,3 +510,26 @@ def nms(y, nc, conf_thres, iou_thres, classes, agnostic, multi_label, max_det):
     lib.call("yolo_nms", _p(y), dt(y), bs, nc, m, float(conf_thres), float(iou_thres), ctypes.cast(arr, ctypes.c_void_p),
              len(cl), int(agnostic), int(multi_label), int(max_det), _p(rows), _p(counts), _p(status), _p(ws), _stream(y))
     return rows, counts, status
+
+
+def val_select(y, nc, conf_threshold, top_k):
+    """decode_predictions' per-image selection on the decoded head output y (N, 4+nc, M):
+    -> (rows fp32 [N][top_k][6] = cx, cy, w, h, cls, score (zero padded), counts int32 [N])."""
+    n, _, m = y.shape
+    y = y.contiguous()
+    ws = torch.empty(lib.query("yolo_val_workspace_bytes", n, m, top_k), dtype=torch.uint8, device=y.device)
+    rows = torch.empty((n, top_k, 6), dtype=torch.float32, device=y.device)
+    count = torch.empty(n, dtype=torch.int32, device=y.device)
+    lib.call("yolo_val_select", _p(y), dt(y), n, nc, m, float(conf_threshold), top_k, _p(rows), _p(count), _p(ws), _stream(y))
+    return rows, count
+
+
+def val_match(rows, count, gt, gt_off, iou_threshold, nc, skip_empty_gt, counters, status):
+    """DetectionMetrics.update for a batch: rows/count from val_select (or any fp32 [N][K][>=5 of 6] rows), gt fp32
+    [total][5], gt_off int32 [N+1]; accumulates into the int64 counters [5 + 4 nc]."""
+    n, k, six = rows.shape
+    assert six == 6 and rows.dtype == torch.float32 and rows.is_contiguous()
+    assert gt.dtype == torch.float32 and gt.is_contiguous() and gt_off.dtype == torch.int32 and count.dtype == torch.int32
+    assert counters.dtype == torch.int64 and counters.numel() == 5 + 4 * nc
+    lib.call("yolo_val_match", _p(rows), _p(count), n, k, _p(gt), _p(gt_off), float(iou_threshold), nc, int(skip_empty_gt),
+             _p(counters), _p(status), _stream(rows))

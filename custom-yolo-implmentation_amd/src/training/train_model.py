@@ -19,25 +19,20 @@ from src.training.metrics import DetectionMetrics
 from src.training.utils_train import save_checkpoint
 
 
-def decode_predictions(preds, anchors, strides, conf_threshold=0.25, top_k=100, num_classes=171):
-    """Raw head output -> per image (k, 5) [cx, cy, w, h, class]: DFL expectation -> xywh * stride (one fused
-    kernel), sigmoid best class, confidence filter, top-k by score; no NMS (reference :14-142)."""
-    n, cp, m = preds.shape
-    nc = cp - 64
+def decode_predictions_packed(preds, anchors, strides, conf_threshold=0.25, top_k=100):
+    """Raw head output -> (rows fp32 [N][top_k][6] = cx, cy, w, h, class, score, zero padded; counts int32 [N]), all
+    on the device: DFL expectation -> xywh * stride (yolo_head_decode), sigmoid best class, `>= conf`, top-k by score
+    (yolo_val_select); no NMS, no per-image launches, no host sync.  Reference :14-142."""
+    nc = preds.shape[1] - 64
     y = ops.head_decode(preds, anchors, strides, nc)            # (N, 4+nc, M): boxes + raw class logits
-    out = []
-    for b in range(n):
-        score, cls = y[b, 4:].transpose(0, 1).sigmoid().max(dim=1)
-        keep = score >= conf_threshold
-        boxes, score, cls = y[b, :4].transpose(0, 1)[keep], score[keep], cls[keep]
-        if boxes.numel() == 0:
-            out.append(torch.zeros(0, 5, device=preds.device))
-            continue
-        if score.numel() > top_k:
-            top = torch.topk(score, top_k)[1]
-            boxes, cls = boxes[top], cls[top]
-        out.append(torch.cat([boxes, cls.unsqueeze(1).to(boxes.dtype)], dim=1).float())
-    return out
+    return ops.val_select(y, nc, conf_threshold, top_k)
+
+
+def decode_predictions(preds, anchors, strides, conf_threshold=0.25, top_k=100, num_classes=171):
+    """Reference signature (:14): list of per-image (k, 5) [cx, cy, w, h, class] fp32 tensors (one host sync for the
+    N counts).  Order: anchor order when at most top_k anchors pass, else descending score."""
+    rows, count = decode_predictions_packed(preds, anchors, strides, conf_threshold, top_k)
+    return [rows[b, :c, :5] if c else torch.zeros(0, 5, device=preds.device) for b, c in enumerate(count.tolist())]
 
 
 def _make_scaler(precision, distributed_mode, device, rank):
@@ -76,10 +71,9 @@ def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimi
                 loss.backward()
                 optimizer.step()
         elif metrics is not None:
-            for pred, gt in zip(decode_predictions(preds, anchors, strides, conf_threshold=conf_threshold,
-                                                   num_classes=num_classes), gt_box):
-                if gt.numel() > 0:
-                    metrics.update(pred, gt)
+            # one select + one matching launch per batch; images without ground truth are skipped (reference :326-328)
+            rows, count = decode_predictions_packed(preds, anchors, strides, conf_threshold=conf_threshold)
+            metrics.update_batch(rows, count, gt_box, skip_empty_targets=True)
         for k, key in enumerate(("total_loss", "box_loss", "cls_loss")):
             sums[k] += loss_dict[key]
         bar.set_postfix({"Loss": f"{sums[0] / (i + 1):.4f}", "Box": f"{sums[1] / (i + 1):.4f}",

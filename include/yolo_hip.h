@@ -118,6 +118,14 @@ int yolo_nms_capacity(int M, int nc, int multi_label);
 size_t yolo_nms_workspace_bytes(int bs, int M, int nc, int multi_label);
 int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, float iou_thres, const int* classes, int n_classes, int agnostic, int multi_label, int max_det, float* out, int* out_count, int* status, void* workspace, hipStream_t st);
 
+/* ---- validation on device: decode_predictions' per-image select (train_model.py:14-142: sigmoid best class,
+   `>= conf`, top-k by score; rows = cx, cy, w, h, cls, score) on yolo_head_decode's output, and DetectionMetrics.update
+   (metrics.py:68-157: greedy same-class IoU matching in prediction order) into int64 counters
+   [total_pred, total_gt, tp, fp, fn, class_tp[nc], class_fp[nc], class_fn[nc], class_gt[nc]] */
+size_t yolo_val_workspace_bytes(int N, int M, int top_k);
+int yolo_val_select(const void* y, int dtype, int N, int nc, int M, float conf, int top_k, float* out, int* out_count, void* workspace, hipStream_t st);
+int yolo_val_match(const float* pred, const int* count, int N, int top_k, const float* gt, const int* gt_off, double iou_thr, int nc, int skip_empty_gt, long long* counters, int* status, hipStream_t st);
+
 /* ---- hardware self-tests (instruction semantics the tiled kernels assume; tests/test_gpu_selftest.py; no reference counterpart: model_blocks.py:1) */
 int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st);
 int yolo_selftest_glds(const void* in128x16, void* out64x16, hipStream_t st);

@@ -127,3 +127,93 @@ def decode_predictions(preds, anchors, strides, conf_threshold=0.25, top_k=100):
             bb, cc = bb[top], cc[top]
         res.append(torch.cat([bb, cc.unsqueeze(1).float()], 1))
     return res
+
+
+# ---- validation counters: reference src/training/metrics.py ------------------------------------------------
+def box_iou_batch(b1, b2):
+    """(N,4) x (M,4) centre-xywh -> (N,M) IoU, fp32, 1e-6 added to the union.  metrics.py:6-41, op by op."""
+    def corners(b):
+        return b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+    ax1, ay1, ax2, ay2 = corners(b1)
+    bx1, by1, bx2, by2 = corners(b2)
+    w = (torch.min(ax2[:, None], bx2[None]) - torch.max(ax1[:, None], bx1[None])).clamp(min=0)
+    h = (torch.min(ay2[:, None], by2[None]) - torch.max(ay1[:, None], by1[None])).clamp(min=0)
+    inter = w * h
+    a1, a2 = (ax2 - ax1) * (ay2 - ay1), (bx2 - bx1) * (by2 - by1)
+    return inter / (a1[:, None] + a2[None] - inter + 1e-6)
+
+
+class MetricCounters:
+    """DetectionMetrics state + update as plain loops.  metrics.py:52-66 (reset), :68-157 (update)."""
+
+    def __init__(self, num_classes, iou_threshold=0.5):
+        self.nc, self.thr = num_classes, iou_threshold
+        self.total_predictions = self.total_ground_truths = 0
+        self.tp = self.fp = self.fn = 0
+        self.class_tp, self.class_fp = np.zeros(num_classes, np.int64), np.zeros(num_classes, np.int64)
+        self.class_fn, self.class_gt = np.zeros(num_classes, np.int64), np.zeros(num_classes, np.int64)
+
+    def _ok(self, c):
+        return 0 <= c < self.nc
+
+    def update(self, predictions, targets):
+        n = predictions.shape[0] if predictions.numel() else 0
+        m = targets.shape[0] if targets.numel() else 0
+        if n == 0 and m == 0:                                   # :80
+            return
+        pc = [int(v) for v in predictions[:, 4].long()] if n else []
+        tc = [int(v) for v in targets[:, 4].long()] if m else []
+        if n == 0:                                              # :91-98: totals are NOT advanced on this path
+            self.fn += m
+            for c in tc:
+                if self._ok(c):
+                    self.class_fn[c] += 1
+                    self.class_gt[c] += 1
+            return
+        if m == 0:                                              # :100-106
+            self.fp += n
+            for c in pc:
+                if self._ok(c):
+                    self.class_fp[c] += 1
+            return
+        iou = box_iou_batch(predictions[:, :4].float(), targets[:, :4].float())
+        taken = set()
+        for i in range(n):                                      # :117-145, predictions in the given order
+            best, bj = 0.0, -1
+            for j in range(m):
+                if j in taken:
+                    continue
+                if pc[i] == tc[j] and float(iou[i, j]) > best:  # strict: first index wins a tie, IoU 0 never matches
+                    best, bj = float(iou[i, j]), j
+            if best >= self.thr and bj >= 0:                    # python float (double) comparison
+                self.tp += 1
+                taken.add(bj)
+                if self._ok(pc[i]):
+                    self.class_tp[pc[i]] += 1
+            else:
+                self.fp += 1
+                if self._ok(pc[i]):
+                    self.class_fp[pc[i]] += 1
+        self.fn += m - len(taken)                               # :148-156
+        for j in range(m):
+            if self._ok(tc[j]):
+                self.class_gt[tc[j]] += 1
+                if j not in taken:
+                    self.class_fn[tc[j]] += 1
+        self.total_predictions += n
+        self.total_ground_truths += m
+
+    def scalars(self):
+        return [self.total_predictions, self.total_ground_truths, self.tp, self.fp, self.fn]
+
+    def compute(self):                                          # :159-191
+        p = self.tp / (self.tp + self.fp + 1e-6)
+        r = self.tp / (self.tp + self.fn + 1e-6)
+        # the reference keeps the per-class counters as fp32 tensors: precision is an fp32 quotient
+        ctp, cfp = torch.from_numpy(self.class_tp).float(), torch.from_numpy(self.class_fp).float()
+        cp = ctp / (ctp + cfp + 1e-6)
+        valid = torch.from_numpy(self.class_gt > 0)
+        return {"precision": float(p), "recall": float(r), "f1_score": float(2 * (p * r) / (p + r + 1e-6)),
+                "mAP": cp[valid].mean().item() if valid.sum() > 0 else 0.0, "true_positives": int(self.tp),
+                "false_positives": int(self.fp), "false_negatives": int(self.fn),
+                "total_predictions": int(self.total_predictions), "total_ground_truths": int(self.total_ground_truths)}

@@ -296,12 +296,41 @@ def nms(y, nc, conf_thres, iou_thres, classes, agnostic, multi_label, max_det):
     return rows, counts, torch.zeros(1, dtype=torch.int32)
 
 
+def val_select(y, nc, conf_threshold, top_k):
+    """rows [N][top_k][6] = cx, cy, w, h, cls, score; counts -- train_model.py:102-139 on the decoded tensor"""
+    n, _, m = y.shape
+    rows = torch.zeros(n, top_k, 6)
+    counts = torch.zeros(n, dtype=torch.int32)
+    for b in range(n):
+        sc, ci = y[b, 4:].transpose(0, 1).sigmoid().max(1)
+        keep = sc >= conf_threshold
+        bb, ss, cc = y[b, :4].transpose(0, 1)[keep], sc[keep], ci[keep]
+        if ss.numel() > top_k:
+            top = opost.stable_desc_order(ss.float())[:top_k]
+            bb, ss, cc = bb[top], ss[top], cc[top]
+        k = ss.numel()
+        rows[b, :k, :4], rows[b, :k, 4], rows[b, :k, 5] = bb.float(), cc.float(), ss.float()
+        counts[b] = k
+    return rows, counts
+
+
+def val_match(rows, count, gt, gt_off, iou_threshold, nc, skip_empty_gt, counters, status):
+    mc = opost.MetricCounters(nc, iou_threshold)
+    for b in range(rows.shape[0]):
+        t = gt[int(gt_off[b]):int(gt_off[b + 1])]
+        if skip_empty_gt and t.shape[0] == 0:
+            continue
+        mc.update(rows[b, :int(count[b]), :5], t)
+    counters += torch.tensor(mc.scalars() + mc.class_tp.tolist() + mc.class_fp.tolist() + mc.class_fn.tolist()
+                             + mc.class_gt.tolist(), dtype=torch.int64)
+
+
 LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "zero_", "fill_", "pack_weights", "conv_fwd",
           "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad", "bn_stats_acc", "bn_finalize_acc", "bn_act_fwd_train", "bn_act_bwd_train",
           "conv_dgrad", "conv_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "bn_train_stats", "bn_eval_coeffs",
           "bn_act_fwd", "bn_act_bwd", "bn_act_bwd_eval", "channel_sum", "maxpool5_fwd", "maxpool5_bwd",
           "upsample2x_fwd", "upsample2x_bwd", "attn_fwd", "attn_bwd", "loss_fwd_bwd", "scale_inplace", "head_decode",
-          "dfl_expect", "nms"]
+          "dfl_expect", "nms", "val_select", "val_match"]
 
 
 def install(monkeypatch):

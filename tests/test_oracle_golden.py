@@ -202,3 +202,26 @@ def test_model_n320_eval_fuse_inference():
         assert dt.shape == want.shape, (i, dt.shape, want.shape)
         close(dt, want, rtol=1e-4, atol=1e-3, what=f"det{i}")
         assert torch.equal(dt[:, 5], want[:, 5])
+
+
+def _metric_cases(gd):
+    po, go = gd["pred_off"], gd["gt_off"]
+    return [(gd["pred"][po[i]:po[i + 1]], gd["gt"][go[i]:go[i + 1]]) for i in range(len(po) - 1)]
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.45])
+def test_detection_metrics_counters(thr):
+    """oracle MetricCounters vs the reference's DetectionMetrics (metrics.py:68-191): exact counters"""
+    gd = load_golden("metrics")
+    cases = _metric_cases(gd)
+    close(op.box_iou_batch(cases[0][0][:, :4], cases[0][1][:, :4]), gd["iou_first"], rtol=0, atol=0, what="iou")
+    m = op.MetricCounters(int(gd["num_classes"]), thr)
+    tag = f"thr{thr}"
+    for i, (p, t) in enumerate(cases):
+        m.update(p, t)
+        assert m.scalars() == gd[tag + ":scalars_after_each"][i].tolist(), f"image {i}"
+    for name, arr in (("class_tp", m.class_tp), ("class_fp", m.class_fp), ("class_fn", m.class_fn), ("class_gt", m.class_gt)):
+        assert arr.tolist() == gd[f"{tag}:{name}"].long().tolist(), name
+    res = m.compute()
+    for k, v in zip(gd[tag + ":compute_keys"], gd[tag + ":compute_vals"].tolist()):
+        assert abs(res[str(k)] - v) <= 1e-12 + 1e-7 * abs(v), (k, res[str(k)], v)

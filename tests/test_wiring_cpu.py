@@ -127,3 +127,23 @@ def test_product_refuses_cpu_tensors_without_emulation(monkeypatch):
     from src.hipops import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.conv_fwd(ops.new_nhwc(1, 8, 4, 4, torch.float32, "cpu"), torch.zeros(8 * 32), None, 8, 1, 1)
+
+
+def test_validation_host_wiring():
+    """decode_predictions / DetectionMetrics host logic (packing, offsets, counter layout, compute) against the
+    reference's goldens, with the two HIP leaves emulated"""
+    from src.training.metrics import DetectionMetrics
+    from src.training.train_model import decode_predictions
+    gd = load_golden("decode_val")
+    out = decode_predictions(gd["preds"], gd["anchors"], gd["strides"], conf_threshold=0.6, top_k=10)
+    for i in range(2):
+        close(out[i], gd[f"out{i}"].reshape(-1, 5), what=f"decode{i}")
+    gm = load_golden("metrics")
+    po, go = gm["pred_off"], gm["gt_off"]
+    m = DetectionMetrics(int(gm["num_classes"]), 0.5)
+    for i in range(len(po) - 1):
+        m.update(gm["pred"][po[i]:po[i + 1]], gm["gt"][go[i]:go[i + 1]])
+    res = m.compute()
+    for k, v in zip(gm["thr0.5:compute_keys"], gm["thr0.5:compute_vals"].tolist()):
+        assert abs(res[str(k)] - v) <= 1e-12 + 1e-7 * abs(v), (k, res[str(k)], v)
+    assert m.class_tp.tolist() == gm["thr0.5:class_tp"].long().tolist()
