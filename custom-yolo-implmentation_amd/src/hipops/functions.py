@@ -2,6 +2,8 @@
 reference spells as several ATen ops; the forward saves exactly what its hand-written backward needs.
 All leaf calls go through the `ops` module namespace (tests swap leaves for a torch emulation to check
 this wiring on a machine without a GPU; the product never does)."""
+import os
+
 import torch
 
 from . import ops
@@ -35,16 +37,67 @@ FOLD_BN_FINALIZE = True     # BN scale/shift are derived in the prologue of the 
 OVERLAP_WGRAD = True        # run a conv's weight gradient on a side stream, concurrently with its data gradient
 
 
+LAZY_WGRAD_JOIN = False     # set by a caller that owns the whole backward (TrainStepRunner) and joins at its end
+# convs per cross-stream sync point in lazy mode.  Measured on preset s (img/s): per-layer fork/join 2238, 1: 2275,
+# 2: 2320, 4: 2339, 8: 2354-2368, 12: 2330, 16: 2322, 32: 2312, all at the end: 2217 (dy has left the caches by then);
+# grouping by queued bytes instead of by count was worse
+WGRAD_GROUP = int(os.environ.get("YOLO_WGRAD_GROUP", "8"))
+_INFLIGHT = {}              # device -> [(keepalive, fn)] of the work still running on the side stream
+_QUEUED = {}                # device -> [(keepalive, fn)] not yet issued
+
+
+def _issue_wgrads(dev, cur, side):
+    """One sync point: join what runs on the side stream, fork, issue every queued piece of work there."""
+    if _INFLIGHT.get(dev):
+        cur.wait_stream(side)
+    jobs = _QUEUED.pop(dev, [])
+    _INFLIGHT[dev] = jobs                   # the previous group's inputs may be reused from here on
+    if jobs:
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _, fn in jobs:
+                fn()
+
+
+def defer_to_side(dev, keepalive, fn):
+    """In a LAZY_WGRAD_JOIN backward: queue `fn` (parameter-gradient work nothing downstream in backward reads; it
+    must write into tensors allocated by the caller) for the side stream and return True; `keepalive` holds its
+    inputs until the join after it ran.  Otherwise return False (the caller runs it inline)."""
+    if not (LAZY_WGRAD_JOIN and OVERLAP_WGRAD and dev.type == "cuda"):
+        return False
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(dev)
+    q = _QUEUED.setdefault(dev, [])
+    q.append((keepalive, fn))
+    if len(q) >= WGRAD_GROUP:
+        _issue_wgrads(dev, torch.cuda.current_stream(dev), side)
+    return True
+
+
 def _wgrad_overlapped(x, dy, k, stride, w_dtype, dgrad_fn):
     """(dx, dw) of a dense conv.  The two gradients are independent: the weight gradient is issued on a side HIP
     stream (fork after dy is ready, join before returning), so on the small maps -- kernels of 100-400 workgroups on
-    a 256-CU chip -- the two run side by side; inside a captured step this becomes a fork/join in the hipGraph."""
+    a 256-CU chip -- the two run side by side; inside a captured step this becomes a fork/join in the hipGraph.
+    A cross-stream sync point costs ~10 us of idle GPU in the replayed graph (tools/trace_gaps.py).  With
+    LAZY_WGRAD_JOIN the join of a layer is taken at the fork of a LATER conv's backward (the side stream has long
+    finished by then) and WGRAD_GROUP convs share one sync point; x and dy of queued / running weight gradients are
+    kept alive until that join, and dw is valid only after join_wgrad_stream()."""
     if not (OVERLAP_WGRAD and x.is_cuda):
         return dgrad_fn(), ops.conv_wgrad(x, dy, k, stride, w_dtype)
-    cur = torch.cuda.current_stream(x.device)
-    side = _SIDE.get(x.device)
+    dev = x.device
+    cur = torch.cuda.current_stream(dev)
+    side = _SIDE.get(dev)
     if side is None:
-        side = _SIDE[x.device] = torch.cuda.Stream(x.device)
+        side = _SIDE[dev] = torch.cuda.Stream(dev)
+    if LAZY_WGRAD_JOIN:
+        dw = torch.empty((dy.shape[1], x.shape[1], k, k), dtype=w_dtype, device=dev)
+        fn = lambda: ops.conv_wgrad(x, dy, k, stride, dw.dtype, out=dw)
+        if not defer_to_side(dev, (x, dy), fn):
+            fn()
+        # a second tensor object on the same storage: autograd's AccumulateGrad clones a gradient it cannot steal
+        # (use count > 1), and that clone would read dw before the side stream has written it
+        return dgrad_fn(), dw.detach()
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         dw = ops.conv_wgrad(x, dy, k, stride, w_dtype)
@@ -52,6 +105,21 @@ def _wgrad_overlapped(x, dy, k, stride, w_dtype, dgrad_fn):
     cur.wait_stream(side)
     dw.record_stream(cur)           # allocated on the side stream, consumed (optimizer / reducer) on this one
     return dx, dw
+
+
+def join_wgrad_stream(device):
+    """End of a LAZY_WGRAD_JOIN backward: issue what is still queued and wait for the side stream."""
+    device = torch.device(device)
+    if device.index is None and device.type == "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+    side = _SIDE.get(device)
+    if side is None:
+        return
+    cur = torch.cuda.current_stream(device)
+    _issue_wgrads(device, cur, side)
+    if _INFLIGHT.get(device):
+        cur.wait_stream(side)
+    _INFLIGHT[device] = []
 
 
 class BnArena:
@@ -157,7 +225,14 @@ class ConvBnAct(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = ops.dw_dgrad(dy, _f32(weight).reshape(weight.shape[0], 9))
             if ctx.needs_input_grad[1]:
-                dw = ops.dw_wgrad(x, dy).to(weight.dtype)
+                if weight.dtype == torch.float32 and x.is_cuda and LAZY_WGRAD_JOIN:
+                    dwb = torch.empty((weight.shape[0], 1, 3, 3), dtype=torch.float32, device=x.device)
+                    fn = lambda: ops.dw_wgrad(x, dy, out=dwb)
+                    if not defer_to_side(x.device, (x, dy), fn):
+                        fn()
+                    dw = dwb.detach()
+                else:
+                    dw = ops.dw_wgrad(x, dy).to(weight.dtype)
         else:
             dgrad = lambda: ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride)
             if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
@@ -197,10 +272,25 @@ class ConvBias(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, x.dtype), cin, h, w, k, stride)
+        lazy = x.is_cuda and LAZY_WGRAD_JOIN
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, dy, k, stride, weight.dtype)
+            if lazy:
+                dwb = torch.empty(weight.shape, dtype=weight.dtype, device=x.device)
+                fn = lambda: ops.conv_wgrad(x, dy, k, stride, dwb.dtype, out=dwb)
+                if not defer_to_side(x.device, (x, dy), fn):
+                    fn()
+                dw = dwb.detach()
+            else:
+                dw = ops.conv_wgrad(x, dy, k, stride, weight.dtype)
         if bdtype is not None and ctx.needs_input_grad[2]:
-            db = ops.channel_sum(dy).to(bdtype)
+            if lazy and bdtype == torch.float32:
+                dbb = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
+                fnb = lambda: ops.channel_sum(dy, out=dbb)
+                if not defer_to_side(x.device, (dy,), fnb):
+                    fnb()
+                db = dbb.detach()
+            else:
+                db = ops.channel_sum(dy).to(bdtype)
         return dx, dw, db, None, None
 
 

@@ -259,7 +259,7 @@ def conv_dgrad(dy, wb, cin, h, w, k, stride):
     return dx
 
 
-def conv_wgrad(x, dy, k, stride, w_dtype):
+def conv_wgrad(x, dy, k, stride, w_dtype, out=None):
     """OIHW weight gradient in w_dtype.  The kernels write per-slab partial matrices into a scratch buffer and a
     reduce pass sums them straight into the OIHW tensor (no memset, no atomics, no separate unpack)."""
     n, cin, h, w, ldx = geom(x)
@@ -267,7 +267,8 @@ def conv_wgrad(x, dy, k, stride, w_dtype):
     args = (n, h, w, cin, oh, ow, cout, k, stride, dt(x), ALGO)
     ws = torch.empty(lib.query("yolo_conv2d_wgrad_ws_elems", _p(x), ldx, _p(dy), ldy, *args), dtype=torch.float32,
                      device=x.device)
-    dw = torch.empty((cout, cin, k, k), dtype=w_dtype, device=x.device)
+    dw = torch.empty((cout, cin, k, k), dtype=w_dtype, device=x.device) if out is None else out
+    assert dw.shape == (cout, cin, k, k) and dw.dtype == w_dtype and dw.is_contiguous()
     lib.call("yolo_conv2d_wgrad", _p(x), ldx, _p(dy), ldy, _p(ws), _p(dw), dt(w_dtype), *args, _stream(x))
     return dw
 
@@ -313,10 +314,11 @@ def dw_dgrad(dy, w9):
     return dx
 
 
-def dw_wgrad(x, dy):
+def dw_wgrad(x, dy, out=None):
     n, c, h, w, ldx = geom(x)
     _, _, _, _, ldy = geom(dy)
-    dw = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=x.device)
+    dw = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=x.device) if out is None else out
+    assert dw.shape == (c, 1, 3, 3) and dw.dtype == torch.float32 and dw.is_contiguous()
     part = torch.empty(lib.query("yolo_dw_wgrad_nslab", n, h) * c * 9, dtype=torch.float32, device=x.device)
     lib.call("yolo_dwconv3x3_wgrad", _p(x), ldx, _p(dy), ldy, _p(dw), _p(part), n, h, w, c, dt(x), _stream(x))
     return dw
@@ -389,14 +391,15 @@ def bn_act_bwd_eval(dout, y, scale, shift, act):
     return dy
 
 
-def channel_sum(x):
+def channel_sum(x, out=None):
     n, c, h, w, ld = geom(x)
     npix = n * h * w
     nblk = lib.query("yolo_reduce_nblk", npix, c)
     part = _f32(nblk * 2 * c, x.device)
     st = _stream(x)
     lib.call("yolo_bn_stats", _p(x), ld, npix, c, dt(x), _p(part), nblk, st)
-    out = _f32(c, x.device)
+    out = _f32(c, x.device) if out is None else out
+    assert out.shape == (c,) and out.dtype == torch.float32
     lib.call("yolo_sum_finalize", _p(part), nblk, c, _p(out), st)
     return out
 

@@ -10,9 +10,13 @@ graph 1 = forward + loss + backward + "pack all gradients into the flat communic
 copy, bf16-compressed if asked), then `all_reduce(AVG)` on the flat buffer, then graph 2 = "unpack into the
 gradients" + the (capturable) optimizer step -- a dozen launches per step from the host instead of ~300.
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+
+from src.hipops import functions as F_
 
 
 class TrainStepRunner:
@@ -42,7 +46,17 @@ class TrainStepRunner:
         with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             preds, anchors, strides = self.model(images)
             loss, ld = self.criterion(preds, packed, anchors, strides)
-        loss.backward()
+        if dev_type == "cuda":
+            # one cross-stream sync point per conv instead of two: a layer's weight gradient is joined at the next
+            # layer's fork (nothing reads a gradient before this method returns)
+            F_.LAZY_WGRAD_JOIN = os.environ.get('YOLO_LAZY_JOIN', '1') == '1'
+            try:
+                loss.backward()
+            finally:
+                F_.LAZY_WGRAD_JOIN = False
+            F_.join_wgrad_stream(images.device)
+        else:
+            loss.backward()
         return loss, ld
 
     def _allreduce(self):

@@ -88,6 +88,63 @@ def test_two_graph_data_parallel_step_equals_single_graph_step(pg):
     assert any(not torch.equal(a, c) for a, c in zip(base, comp))
 
 
+@pytest.mark.parametrize("group", [1, 3, 8])
+def test_runner_gradients_equal_plain_autograd(group, monkeypatch):
+    """TrainStepRunner runs the conv weight gradients on a side stream that is joined lazily, several layers per
+    sync point; the gradients it leaves in .grad -- eagerly and after graph replays -- must be those of a plain
+    `loss.backward()`.  (Regression: a gradient tensor that was also referenced by the pending-work queue was CLONED
+    by autograd's AccumulateGrad before the side stream had written it: stale gradients, training still converged.)"""
+    from src.hipops import functions as F_
+    from src.model.losses import PackedTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.graph_step import TrainStepRunner
+    monkeypatch.setattr(F_, "WGRAD_GROUP", group)
+    g = torch.Generator().manual_seed(12)
+    img = torch.randn(2, 3, 160, 160, generator=g).cuda()
+    gts = [torch.cat([torch.rand(3, 2, generator=g) * 160, torch.rand(3, 2, generator=g) * 60 + 8,
+                      torch.randint(0, 80, (3, 1), generator=g).float()], 1).cuda() for _ in range(2)]
+    packed = PackedTargets(gts, img.device)
+    torch.manual_seed(0)
+    model = Model(**NANO, num_classes=80).cuda().train()
+    crit = YoloDFLQFLoss(num_classes=80)
+
+    def grads():
+        return [p.grad.detach().float().clone() for p in model.parameters() if p.grad is not None]
+
+    def plain(image):                                       # plain autograd: per-layer fork/join inside each backward
+        model.zero_grad(set_to_none=True)
+        preds, anchors, strides = model(image)
+        crit(preds, packed, anchors, strides)[0].backward()
+        torch.cuda.synchronize()
+        return grads()
+
+    def check(want, got, what):
+        gmax = max(float(a.abs().max()) for a in want)
+        for a, b in zip(want, got):
+            scale = a.abs().max().clamp_min(1e-3 * gmax)
+            assert (a - b).abs().max() / scale < 1e-3, what
+
+    want = plain(img)
+    plain(torch.randn(2, 3, 160, 160, generator=g).cuda())  # freed blocks now hold ANOTHER batch's gradients
+    opt = torch.optim.AdamW(model.parameters(), lr=0.0, weight_decay=0.0, capturable=True, fused=True)
+    model.zero_grad(set_to_none=True)
+    r = TrainStepRunner(model, crit, opt, "float32", use_graph=False)
+    r._fwd_bwd(img, packed)
+    torch.cuda.synchronize()
+    check(want, grads(), "eager runner step")
+    r = TrainStepRunner(model, crit, opt, "float32", use_graph=True)
+    r.capture(img, packed, warmup=1)
+    with torch.no_grad():                                   # new weights: last replay's gradients are now WRONG ones,
+        for p in model.parameters():                        # and the static gradient buffers are poisoned
+            p.mul_(1.02)
+            if p.grad is not None:
+                p.grad.fill_(1e6)
+    r.step()
+    torch.cuda.synchronize()
+    got = grads()
+    check(plain(img), got, "graph replay")
+
+
 def test_graph_replays_reproduce_the_eager_forward():
     """A captured forward must give the eager result on EVERY replay.  (Regression: the statistics accumulators were
     zeroed by hipMemsetAsync, which a capture turns into a memset node; replays did not always order it before the
