@@ -47,9 +47,10 @@ class TrainStepRunner:
             preds, anchors, strides = self.model(images)
             loss, ld = self.criterion(preds, packed, anchors, strides)
         if dev_type == "cuda":
-            # one cross-stream sync point per conv instead of two: a layer's weight gradient is joined at the next
-            # layer's fork (nothing reads a gradient before this method returns)
-            F_.LAZY_WGRAD_JOIN = os.environ.get('YOLO_LAZY_JOIN', '1') == '1'
+            # parameter-gradient work is queued for the side stream and joined lazily, several layers per cross-stream
+            # sync point (functions._wgrad_overlapped); nothing reads a gradient before this method returns.
+            # YOLO_LAZY_JOIN=0 keeps the per-layer fork/join (diagnosis / A-B runs)
+            F_.LAZY_WGRAD_JOIN = os.environ.get("YOLO_LAZY_JOIN", "1") == "1"
             try:
                 loss.backward()
             finally:
