@@ -5,6 +5,7 @@
 // as 1x1 convolutions on the MFMA kernels.  k = ci*9 + kh*3 + kw is exactly the OIHW flattening, so
 // weights and weight gradients are plain [Cout][27] views padded to 32.
 #include "common.h"
+#include "conv_dev.h"
 
 namespace {
 
@@ -61,6 +62,149 @@ __global__ void k_stem_unpack_dw(const float* __restrict__ dw32, int Cout, P* __
     dw[e] = from_f<P>(dw32[o * 32 + k]);
 }
 
+// ---- fused forward: y = W * unfold(img) straight from the NCHW fp32 image (no column tensor in HBM) --------------------
+// A workgroup owns 128 consecutive output pixels of TWO output rows: the 3 channels x 5 input rows it needs (257
+// columns each) are staged once in LDS, one 16-byte load per lane = one row segment per wave instruction; every lane then gathers its MFMA B fragment
+// (8 consecutive k of one pixel; k = ci*9 + kh*3 + kw, so row = k/3 and column offset = k%3) from LDS and the A
+// fragments (weights [Cout][32], L2-resident) from global memory: one 16x16x32 MFMA per (16 channels x 16 pixels).
+// Epilogue as k_conv_mfma: 8-byte channel groups per lane, BatchNorm batch statistics of the rounded values.
+constexpr int STEM_SEG = 128;
+constexpr int STEM_ROWW = 2 * STEM_SEG + 1;
+constexpr int STEM_IR = 5;          // input rows per channel for TWO output rows (the middle one is shared)
+
+template <typename T, int CT>
+__global__ __launch_bounds__(256) void k_stem_conv(const float* __restrict__ img, const T* __restrict__ wp,
+                                                   T* __restrict__ y, int ldy, float* __restrict__ stats, int N, int H,
+                                                   int W, int OH, int OW, int Cout) {
+    typedef mfma_ops<T> ops;
+    typedef typename ops::frag frag;
+    // rows[ci*5 + ir][4 + c] = input row 2*oh0 - 1 + ir, column 2*ow0 + c (c in [0, 256)); [..][3] = column 2*ow0 - 1
+    __shared__ __attribute__((aligned(16))) float rows[3 * STEM_IR][STEM_ROWW + 7];
+    __shared__ float sacc[2][16 * CT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    const int segs = (OW + STEM_SEG - 1) / STEM_SEG, ohp = (OH + 1) >> 1;
+    const int seg = blockIdx.x % segs;
+    const int t = blockIdx.x / segs;
+    const int oh0 = (t % ohp) * 2, n = t / ohp;
+    const int ow0 = seg * STEM_SEG, iw0 = 2 * ow0 - 1;
+    if ((W & 3) == 0) {
+        // one 16-byte load per lane = one whole row segment per wave instruction
+        for (int r = wave; r < 3 * STEM_IR; r += 4) {
+            const int ci = r / STEM_IR, ir = r - ci * STEM_IR;
+            const int ih = 2 * oh0 + ir - 1;
+            const bool rok = ih >= 0 && ih < H;
+            const float* src = img + (((long)n * 3 + ci) * H + (rok ? ih : 0)) * (long)W + 2 * ow0;
+            const int c = lane * 4;
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (rok && 2 * ow0 + c < W) v = *reinterpret_cast<const float4*>(src + c);      // W % 4 == 0: all four or none
+            *reinterpret_cast<float4*>(&rows[r][4 + c]) = v;
+            if (lane == 0) rows[r][3] = (rok && ow0 > 0) ? src[-1] : 0.f;
+        }
+    } else {
+        for (int idx = tid; idx < 3 * STEM_IR * STEM_ROWW; idx += 256) {
+            const int r = idx / STEM_ROWW, c = idx - r * STEM_ROWW;
+            const int ci = r / STEM_IR, ir = r - ci * STEM_IR;
+            const int ih = 2 * oh0 + ir - 1, iw = iw0 + c;
+            const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+            rows[r][3 + c] = ok ? img[(((long)n * 3 + ci) * H + ih) * (long)W + iw] : 0.f;
+        }
+    }
+    for (int c = tid; c < 2 * 16 * CT; c += 256) (&sacc[0][0])[c] = 0.f;
+    frag a[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) a[ct] = *reinterpret_cast<const frag*>(wp + (long)(ct * 16 + fr) * 32 + kg * 8);
+    __syncthreads();
+    // a wave owns four 16-pixel tiles: tile id wave*4 + i = (output row j) * 8 + (tile within the 128-pixel segment)
+    f32x4 acc[CT][4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tl = wave * 4 + i, j = tl >> 3;
+        const int p = (tl & 7) * 16 + fr;                   // pixel of this lane's B column
+        live[i] = ow0 + p < OW && oh0 + j < OH;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kg * 8 + e;
+            const int ci = k / 9, r3 = k / 3, kh = r3 - ci * 3, kw = k - r3 * 3;
+            v[e] = (k < 27 && live[i]) ? rows[k < 27 ? ci * STEM_IR + 2 * j + kh : 0][2 * p + kw + 3] : 0.f;
+        }
+        frag b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = from_f<T>(v[e]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            acc[ct][i] = ops::mma(a[ct], b, z);
+        }
+    }
+    // lane holds channels ct*16 + kg*4 .. +3 of its tile's pixel fr
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!live[i]) continue;
+        const int tl = wave * 4 + i;
+        T* drow = y + (((long)n * OH + oh0 + (tl >> 3)) * OW + ow0 + (tl & 7) * 16 + fr) * (long)ldy;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ct][i][r];
+            store_pack<T, 4>(drow + ct * 16 + kg * 4, v);
+        }
+    }
+    if (stats != nullptr) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = to_f<T>(from_f<T>(acc[ct][i][r]));      // pixels past the row / image end hold 0
+                    s[r] += v;
+                    q2[r] += v * v;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] = row16_sum(s[r]);
+                q2[r] = row16_sum(q2[r]);
+            }
+            if (fr == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(&sacc[0][ct * 16 + kg * 4 + r], s[r]);
+                    atomicAdd(&sacc[1][ct * 16 + kg * 4 + r], q2[r]);
+                }
+            }
+        }
+        __syncthreads();
+        float* o = stats + (long)(blockIdx.x & 7) * 2 * Cout;
+        for (int c = tid; c < 16 * CT; c += 256) {
+            atomicAdd(o + c, sacc[0][c]);
+            atomicAdd(o + Cout + c, sacc[1][c]);
+        }
+    }
+}
+
+template <typename T>
+int launch_stem_conv(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW,
+                     int Cout, hipStream_t st) {
+    const long blocks = (long)N * ((OH + 1) / 2) * ((OW + STEM_SEG - 1) / STEM_SEG);
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YOLO_ERR_ARG;
+#define STEM_CT(CT) hipLaunchKernelGGL((k_stem_conv<T, CT>), dim3((unsigned)blocks), dim3(256), 0, st, img, (const T*)wp, (T*)y, ldy, stats, N, H, W, OH, OW, Cout)
+    switch (Cout / 16) {
+        case 1: STEM_CT(1); break;
+        case 2: STEM_CT(2); break;
+        case 3: STEM_CT(3); break;
+        case 4: STEM_CT(4); break;
+        case 6: STEM_CT(6); break;
+        case 8: STEM_CT(8); break;
+        default: return YOLO_ERR_ARG;
+    }
+#undef STEM_CT
+    return YOLO_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 extern "C" {
@@ -107,6 +251,23 @@ int yolo_stem_unpack_wgrad(const float* dw32, int Cout, void* dw, int dw_dtype, 
         default: return YOLO_ERR_DTYPE;
     }
     return YOLO_LAUNCH_CHECK();
+}
+
+// 1 if yolo_stem_conv_fwd handles these arguments (fp32 NCHW image, bf16/f16 compute, Cout in {16,32,48,64,96,128})
+int yolo_stem_conv_eligible(int img_dtype, int dtype, int Cout) {
+    const int ct = Cout / 16;
+    return img_dtype == YOLO_F32 && (dtype == YOLO_BF16 || dtype == YOLO_F16) && Cout % 16 == 0 &&
+           (ct == 1 || ct == 2 || ct == 3 || ct == 4 || ct == 6 || ct == 8);
+}
+
+// y[N][OH][OW][ld >= Cout] (dtype) = conv3x3 stride 2 pad 1 of img (N,3,H,W) fp32 NCHW with wp = yolo_stem_pack_weights
+// output ([Cout][32], dtype); stats: optional [8][2][Cout] BatchNorm accumulator (sum, sum of squares of the stored values)
+int yolo_stem_conv_fwd(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW,
+                       int Cout, int dtype, hipStream_t st) {
+    if (!yolo_stem_conv_eligible(YOLO_F32, dtype, Cout) || ldy < Cout) return YOLO_ERR_ARG;
+    if (OH != (H - 1) / 2 + 1 || OW != (W - 1) / 2 + 1) return YOLO_ERR_ARG;
+    if (dtype == YOLO_BF16) return launch_stem_conv<bf16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, st);
+    return launch_stem_conv<f16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, st);
 }
 
 }  // extern "C"

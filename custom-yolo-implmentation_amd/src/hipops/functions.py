@@ -46,6 +46,14 @@ _INFLIGHT = {}              # device -> [(keepalive, fn)] of the work still runn
 _QUEUED = {}                # device -> [(keepalive, fn)] not yet issued
 
 
+def side_stream(dev):
+    """The one auxiliary HIP stream per device (graph capture of more forked streams is not reliable on this stack)."""
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(dev)
+    return side
+
+
 def _issue_wgrads(dev, cur, side):
     """One sync point: join what runs on the side stream, fork, issue every queued piece of work there."""
     if _INFLIGHT.get(dev):
@@ -163,7 +171,14 @@ class ConvBnAct(torch.autograd.Function):
         # stem: a 3-channel image feeding a 3x3/2 conv is unfolded once (from NCHW directly) and then
         # runs as a 1x1 conv over K = 32 columns; x (saved for wgrad) becomes that column tensor
         stem = (not depthwise and weight.shape[1] == 3 and k == 3 and stride == 2 and not ctx.needs_input_grad[0])
-        if stem:
+        # Without a weight gradient to compute (inference, frozen stem) the conv reads the NCHW image directly.  In
+        # training the unfolded tensor is needed by the weight gradient anyway; the fused forward plus an unfold in
+        # backward was 0.5 % SLOWER per step (the step is bound by total kernel time, not by the forward chain).
+        stem_fused = stem and x.is_cuda and not ctx.needs_input_grad[1] and ops.stem_conv_eligible(x, T, cout)
+        if stem_fused:
+            x = x if x.is_contiguous() else x.contiguous()
+            y = ops.stem_conv_fwd(x, ops.stem_pack_weights(weight, T), cout, T, acc_f)
+        elif stem:
             x = ops.stem_im2col(x, T)
             y = ops.conv_fwd(x, ops.stem_pack_weights(weight, T), None, cout, 1, 1, acc_f)
         elif depthwise:
@@ -220,7 +235,15 @@ class ConvBnAct(torch.autograd.Function):
         n, cin, h, w = xshape
         if stem:
             if ctx.needs_input_grad[1]:
-                dw = ops.stem_unpack_wgrad(ops.conv_wgrad(x, dy, 1, 1, torch.float32), weight.dtype)
+                def stem_dw(out=None):          # x is the unfolded column tensor
+                    return ops.stem_unpack_wgrad(ops.conv_wgrad(x, dy, 1, 1, torch.float32), weight.dtype, out)
+                if x.is_cuda and LAZY_WGRAD_JOIN:
+                    dwb = torch.empty(weight.shape, dtype=weight.dtype, device=x.device)
+                    if not defer_to_side(x.device, (x, dy), lambda: stem_dw(dwb)):
+                        stem_dw(dwb)
+                    dw = dwb.detach()
+                else:
+                    dw = stem_dw()
         elif depthwise:
             if ctx.needs_input_grad[0]:
                 dx = ops.dw_dgrad(dy, _f32(weight).reshape(weight.shape[0], 9))

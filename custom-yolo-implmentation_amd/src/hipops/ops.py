@@ -273,15 +273,33 @@ def conv_wgrad(x, dy, k, stride, w_dtype, out=None):
     return dw
 
 
-def stem_im2col(img, dtype):
+def stem_im2col(img, dtype, out=None):
     """(N,3,H,W) NCHW image (any float dtype) -> NHWC (N,32,OH,OW) column tensor: K = ci*9+kh*3+kw, 27..31 zero."""
     img = img if img.is_contiguous() else img.contiguous()
     n, c, h, w = img.shape
     assert c == 3
     oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    col = new_nhwc(n, 32, oh, ow, dtype, img.device)
+    col = new_nhwc(n, 32, oh, ow, dtype, img.device) if out is None else out
+    assert tuple(col.shape) == (n, 32, oh, ow) and col.dtype == dtype and geom(col)[4] == 32
     lib.call("yolo_stem_im2col", _p(img), dt(img), _p(col), dt(dtype), n, h, w, oh, ow, _stream(img))
     return col
+
+
+def stem_conv_eligible(img, dtype, cout):
+    return img.dtype == torch.float32 and dtype in _DT and \
+        bool(lib.query("yolo_stem_conv_eligible", dt(img), dt(dtype), cout))
+
+
+def stem_conv_fwd(img, wp, cout, dtype, stats_acc=None):
+    """(N,3,H,W) fp32 NCHW image -> NHWC (N,cout,OH,OW) of dtype: 3x3 stride-2 pad-1 conv with the [cout][32] matrix of
+    stem_pack_weights, no column tensor; optionally accumulates the BatchNorm batch statistics like conv_fwd."""
+    img = img if img.is_contiguous() else img.contiguous()
+    n, c, h, w = img.shape
+    assert c == 3
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = new_nhwc(n, cout, oh, ow, dtype, img.device)
+    lib.call("yolo_stem_conv_fwd", _p(img), _p(wp), _p(y), cout, _p(stats_acc), n, h, w, oh, ow, cout, dt(dtype), _stream(img))
+    return y
 
 
 def stem_pack_weights(w, dtype):
@@ -292,10 +310,11 @@ def stem_pack_weights(w, dtype):
     return out
 
 
-def stem_unpack_wgrad(dw32, w_dtype):
+def stem_unpack_wgrad(dw32, w_dtype, out=None):
     """fp32 (Cout,32,1,1) gradient of the padded 1x1 weights -> (Cout,3,3,3) in the parameter dtype."""
     cout = dw32.shape[0]
-    dw = torch.empty((cout, 3, 3, 3), dtype=w_dtype, device=dw32.device)
+    dw = torch.empty((cout, 3, 3, 3), dtype=w_dtype, device=dw32.device) if out is None else out
+    assert dw.shape == (cout, 3, 3, 3) and dw.dtype == w_dtype and dw.is_contiguous()
     lib.call("yolo_stem_unpack_wgrad", _p(dw32), cout, _p(dw), dt(w_dtype), _stream(dw32))
     return dw
 

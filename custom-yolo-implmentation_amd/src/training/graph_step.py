@@ -43,21 +43,19 @@ class TrainStepRunner:
     # -------------------------------------------------------------------------------------------
     def _fwd_bwd(self, images, packed):
         dev_type = images.device.type
-        with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            preds, anchors, strides = self.model(images)
-            loss, ld = self.criterion(preds, packed, anchors, strides)
-        if dev_type == "cuda":
-            # parameter-gradient work is queued for the side stream and joined lazily, several layers per cross-stream
-            # sync point (functions._wgrad_overlapped); nothing reads a gradient before this method returns.
-            # YOLO_LAZY_JOIN=0 keeps the per-layer fork/join (diagnosis / A-B runs)
-            F_.LAZY_WGRAD_JOIN = os.environ.get("YOLO_LAZY_JOIN", "1") == "1"
-            try:
-                loss.backward()
-            finally:
-                F_.LAZY_WGRAD_JOIN = False
-            F_.join_wgrad_stream(images.device)
-        else:
+        # parameter-gradient work is queued for the side stream and joined lazily, several layers per cross-stream
+        # sync point (functions._wgrad_overlapped); nothing reads a gradient before this method returns.
+        # YOLO_LAZY_JOIN=0 keeps the per-layer fork/join (diagnosis / A-B runs)
+        F_.LAZY_WGRAD_JOIN = dev_type == "cuda" and os.environ.get("YOLO_LAZY_JOIN", "1") == "1"
+        try:
+            with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                preds, anchors, strides = self.model(images)
+                loss, ld = self.criterion(preds, packed, anchors, strides)
             loss.backward()
+        finally:
+            F_.LAZY_WGRAD_JOIN = False
+            if dev_type == "cuda":
+                F_.join_wgrad_stream(images.device)
         return loss, ld
 
     def _allreduce(self):

@@ -71,6 +71,9 @@ int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws
 int yolo_stem_im2col(const void* img, int img_dtype, void* col, int col_dtype, int N, int H, int W, int OH, int OW, hipStream_t st);
 int yolo_stem_pack_weights(const void* w, int w_dtype, int Cout, void* out, int out_dtype, hipStream_t st);
 int yolo_stem_unpack_wgrad(const float* dw32, int Cout, void* dw, int dw_dtype, hipStream_t st);
+/* fused stem forward: conv straight from the NCHW fp32 image (no column tensor), BatchNorm statistics in the epilogue */
+int yolo_stem_conv_eligible(int img_dtype, int dtype, int Cout);
+int yolo_stem_conv_fwd(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW, int Cout, int dtype, hipStream_t st);
 /* depthwise 3x3 (groups == channels: model_blocks.py:183, head.py:56,58) */
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype, hipStream_t st);
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int dtype, hipStream_t st);

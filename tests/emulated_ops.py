@@ -131,7 +131,7 @@ def stem_pack_weights(w, dtype):
     return F.pad(w.detach().reshape(w.shape[0], 27), (0, 5)).reshape(w.shape[0], 32, 1, 1).to(dtype)
 
 
-def stem_unpack_wgrad(dw32, w_dtype):
+def stem_unpack_wgrad(dw32, w_dtype, out=None):
     return dw32.reshape(dw32.shape[0], 32)[:, :27].reshape(-1, 3, 3, 3).to(w_dtype)
 
 

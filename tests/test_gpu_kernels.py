@@ -145,6 +145,30 @@ def test_stem_unfold_path(dtype, h, w):
     check(dw, dw_ref, torch.float32, "stem wgrad", mult=4.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cout,h,w", [(16, 32, 32), (32, 17, 23), (64, 640, 322), (48, 9, 515), (96, 6, 6), (128, 34, 258)])
+def test_stem_fused_conv(dtype, cout, h, w):
+    """conv straight from the NCHW fp32 image == the unfold + 1x1 path (same rounded operands, fp32 accumulation),
+    odd sizes, rows longer than one 128-pixel segment, every channel-tile count; statistics of the stored values"""
+    o = ops()
+    img = rnd(2, 3, h, w, seed=18)
+    wt = rnd(cout, 3, 3, 3, seed=19, scale=0.2)
+    assert o.stem_conv_eligible(img.to(DEV), dtype, cout)
+    wp = o.stem_pack_weights(wt.to(DEV), dtype)
+    acc = o.bn_acc_new(cout, DEV)
+    y = o.stem_conv_fwd(img.to(DEV), wp, cout, dtype, acc)
+    col = o.stem_im2col(img.to(DEV), dtype)
+    acc2 = o.bn_acc_new(cout, DEV)
+    y2 = o.conv_fwd(col, wp, None, cout, 1, 1, acc2)
+    y_ref = emu.conv_fwd(nhwc(img.to(dtype)), emu.pack_weights(wt, 3, 2, 0, dtype), None, cout, 3, 2)
+    check(y, y_ref, dtype, "fused stem == 3x3/2 conv")
+    assert torch.equal(y.cpu(), y2.cpu()), "fused stem differs from the unfold path"
+    st = acc.view(o.BN_REPL, 2, cout).sum(0).cpu()
+    yf = y.float().cpu()
+    want = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))])
+    assert torch.allclose(st, want, rtol=2e-4, atol=1e-3 * float(want.abs().max())), (st - want).abs().max()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("c,h,w", [(16, 12, 12), (24, 7, 9), (128, 10, 10)])
 def test_depthwise(dtype, c, h, w):
