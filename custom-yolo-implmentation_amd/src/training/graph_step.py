@@ -46,7 +46,10 @@ class TrainStepRunner:
         # parameter-gradient work is queued for the side stream and joined lazily, several layers per cross-stream
         # sync point (functions._wgrad_overlapped); nothing reads a gradient before this method returns.
         # YOLO_LAZY_JOIN=0 keeps the per-layer fork/join (diagnosis / A-B runs)
-        F_.LAZY_WGRAD_JOIN = dev_type == "cuda" and os.environ.get("YOLO_LAZY_JOIN", "1") == "1"
+        # Only with empty .grad fields: autograd would ADD a new gradient to an existing one right away, on this
+        # stream, before the side stream has produced it.
+        F_.LAZY_WGRAD_JOIN = dev_type == "cuda" and os.environ.get("YOLO_LAZY_JOIN", "1") == "1" and \
+            all(p.grad is None for p in self.params)
         try:
             with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                 preds, anchors, strides = self.model(images)

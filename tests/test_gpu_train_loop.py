@@ -132,6 +132,9 @@ def test_runner_gradients_equal_plain_autograd(group, monkeypatch):
     r._fwd_bwd(img, packed)
     torch.cuda.synchronize()
     check(want, grads(), "eager runner step")
+    r._fwd_bwd(img, packed)                                 # .grad present: autograd accumulates at once, so the runner
+    torch.cuda.synchronize()                                # must not defer the weight gradients of this call
+    check([2 * a for a in want], grads(), "accumulating second backward")
     r = TrainStepRunner(model, crit, opt, "float32", use_graph=True)
     r.capture(img, packed, warmup=1)
     with torch.no_grad():                                   # new weights: last replay's gradients are now WRONG ones,
