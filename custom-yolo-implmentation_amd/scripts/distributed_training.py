@@ -22,7 +22,8 @@ from src.model.losses import YoloDFLQFLoss  # noqa: E402
 from src.model.model_builder import Model  # noqa: E402
 from src.training.distributed_setup import cleanup_distribute_mode, init_distributed_mode  # noqa: E402
 from src.training.train_model import train  # noqa: E402
-from src.training.utils_train import get_optimizer, prepare_ddp_model, prepare_fsdp2_model, prepare_fsdp_model  # noqa: E402
+from src.training.utils_train import (get_optimizer, load_checkpoint, prepare_ddp_model, prepare_fsdp2_model,  # noqa: E402
+                                      prepare_fsdp_model)
 from src.training.wandb_setup import setup_wandb  # noqa: E402
 from src.utils.common import find_latest_checkpoint, get_checkpoint_config  # noqa: E402
 from src.utils.config_loader import load_config  # noqa: E402
@@ -80,11 +81,8 @@ def main(args):
                                              patience=tr_cfg["learning_rate_patience"], factor=tr_cfg["learning_rate_factor"])
         if args.load_from_checkpoint:
             path = find_latest_checkpoint(ckpt_dir)
-            ck = torch.load(path, map_location=args.device)
-            initial_epoch = ck["epoch"]
-            model.load_state_dict(ck["model_state"])
-            optimizer.load_state_dict(ck["optimizer_state"])
-            print(f"[INFO] Loaded model and optimizer from checkpoint at epoch {ck['epoch']} from {path}")
+            initial_epoch = load_checkpoint(model, optimizer, path, map_location=args.device)
+            print(f"[INFO] Loaded model and optimizer from checkpoint at epoch {initial_epoch} from {path}")
         criterion = YoloDFLQFLoss(num_classes=model_cfg["num_classes"], lambda_box=tr_cfg["weights"].get("bbox_loss", 1.5),
                                   lambda_cls=tr_cfg["weights"].get("cls_loss", 1.0))
         train(model=model, train_loader=train_loader, val_loader=val_loader, optimizer=optimizer, scheduler=scheduler,

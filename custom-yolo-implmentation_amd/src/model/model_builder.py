@@ -72,7 +72,10 @@ class Model(nn.Module):
     def load_weights(self, weights_path):
         checkpoint = torch.load(weights_path, map_location=next(self.parameters()).device)
         state = checkpoint["model_state"] if isinstance(checkpoint, dict) and "model_state" in checkpoint else checkpoint
-        self.load_state_dict(state)
+        # checkpoints written under DDP / FSDP1 carry wrapper prefixes ("module." ...): the reference's own load fails on
+        # them (notebooks/04); keys are matched by their canonical names here
+        from src.training.utils_train import canonical_state_dict
+        self.load_state_dict(canonical_state_dict(state))
         print(f"Weights loaded successfully from {weights_path}")
 
     def inference(self, image, conf_thres=0.25, iou_thres=0.45):

@@ -16,7 +16,7 @@ except ImportError:  # pragma: no cover
 from src.hipops import ops
 from src.training.distributed_setup import reduce_values
 from src.training.metrics import DetectionMetrics
-from src.training.utils_train import save_checkpoint
+from src.training.utils_train import _is_sharded, checkpoint_states, save_checkpoint
 
 
 def decode_predictions_packed(preds, anchors, strides, conf_threshold=0.25, top_k=100):
@@ -120,6 +120,8 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, init
         md = metrics.compute()
         scheduler.step(va[0])
 
+        # a sharded model's full state is gathered by a collective: every rank takes part, rank 0 writes
+        states = checkpoint_states(model, optimizer) if _is_sharded(model) else None
         if rank == 0:
             if use_wandb and wandb_instance:
                 wandb_instance.log({"epoch": epoch + 1, "train/epoch_loss": tr[0], "train/epoch_box_loss": tr[1],
@@ -127,7 +129,7 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, init
                                     "val/epoch_cls_loss": va[2], "val/precision": md["precision"],
                                     "val/recall": md["recall"], "val/f1_score": md["f1_score"], "val/mAP": md["mAP"],
                                     "lr": optimizer.param_groups[0]["lr"]})
-            save_checkpoint(model, optimizer, epoch + 1, va[0], checkpoint_dir=checkpoint_dir)
+            save_checkpoint(model, optimizer, epoch + 1, va[0], checkpoint_dir=checkpoint_dir, states=states)
             w = tqdm.write
             w("=" * 80)
             w(f"Epoch {epoch + 1}/{num_epochs} Summary:")

@@ -38,14 +38,67 @@ def get_optimizer(model: nn.Module, lr: float, weight_decay: float, patience: in
     return opt, optim.lr_scheduler.ReduceLROnPlateau(opt, patience=patience, factor=factor)
 
 
+_WRAPPER_SEGMENTS = ("module.", "_fsdp_wrapped_module.", "_orig_mod.", "_checkpoint_wrapped_module.")
+
+
+def canonical_state_dict(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Keys as the bare `Model` names them: wrapper segments that DDP ("module."), FSDP1, torch.compile or
+    activation checkpointing insert are removed, so a checkpoint written under one wrapper loads under any other
+    (the reference's DDP checkpoints carry "module." and fail in its own `Model.load_weights`)."""
+    out = {}
+    for k, v in state.items():
+        for seg in _WRAPPER_SEGMENTS:
+            k = k.replace(seg, "")
+        out[k] = v
+    return out
+
+
+def _is_sharded(model: nn.Module) -> bool:
+    from torch.distributed.tensor import DTensor
+    return isinstance(model, FSDP) or any(isinstance(m, FSDP) for m in model.modules()) or \
+        any(isinstance(p, DTensor) for p in model.parameters())
+
+
+def checkpoint_states(model: nn.Module, optimizer: optim.Optimizer):
+    """(model_state, optimizer_state) to write.  Plain / DDP models: exactly what the reference writes
+    (`model.state_dict()`, `optimizer.state_dict()`; :47-53).  Sharded models (FSDP1, FSDP2): FULL tensors under
+    canonical names, gathered by torch.distributed.checkpoint -- a COLLECTIVE, call it on every rank (the reference
+    pickles each rank's DTensor shards, which nothing can load back: notebooks/04 load error)."""
+    if not _is_sharded(model):
+        return model.state_dict(), optimizer.state_dict()
+    from torch.distributed.checkpoint.state_dict import StateDictOptions, get_state_dict
+    return get_state_dict(model, optimizer, options=StateDictOptions(full_state_dict=True, cpu_offload=True))
+
+
 def save_checkpoint(model: nn.Module, optimizer: optim.Optimizer, epoch: int, val_loss: float,
-                    checkpoint_dir: str = "experiments/checkpoints") -> None:
-    """{epoch, model_state, optimizer_state, val_loss} -> model_epoch_{E}.pth (reference :38-56)."""
+                    checkpoint_dir: str = "experiments/checkpoints", states=None) -> None:
+    """{epoch, model_state, optimizer_state, val_loss} -> model_epoch_{E}.pth (reference :38-56).  `states`: the
+    result of checkpoint_states() when the model is sharded (gathered on all ranks before rank 0 calls this)."""
     os.makedirs(checkpoint_dir, exist_ok=True)
     path = f"{checkpoint_dir}/model_epoch_{epoch}.pth"
-    torch.save({"epoch": epoch, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict(),
-                "val_loss": val_loss}, path)
+    model_state, opt_state = states if states is not None else checkpoint_states(model, optimizer)
+    torch.save({"epoch": epoch, "model_state": model_state, "optimizer_state": opt_state, "val_loss": val_loss}, path)
     print(f"[INFO] Saved checkpoint at {path}")
+
+
+def load_checkpoint(model: nn.Module, optimizer: optim.Optimizer, path: str, map_location="cpu") -> int:
+    """Resume from a checkpoint written by this package or by the reference, under any wrapper: returns the epoch.
+    Model keys are matched by canonical name; sharded models take full tensors through torch.distributed.checkpoint
+    (collective).  The optimizer state is loaded when given and present."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    state = canonical_state_dict(ck["model_state"] if isinstance(ck, dict) and "model_state" in ck else ck)
+    if _is_sharded(model):
+        from torch.distributed.checkpoint.state_dict import StateDictOptions, set_model_state_dict, set_optimizer_state_dict
+        opts = StateDictOptions(full_state_dict=True, cpu_offload=True)
+        set_model_state_dict(model, state, options=opts)
+        if optimizer is not None and isinstance(ck, dict) and "optimizer_state" in ck:
+            set_optimizer_state_dict(model, optimizer, ck["optimizer_state"], options=opts)
+    else:
+        target = model.module if isinstance(model, DDP) else model
+        target.load_state_dict(state)
+        if optimizer is not None and isinstance(ck, dict) and "optimizer_state" in ck:
+            optimizer.load_state_dict(ck["optimizer_state"])
+    return int(ck["epoch"]) if isinstance(ck, dict) and "epoch" in ck else 0
 
 
 def _pin_device(device: str, device_id: int, world_size: int):

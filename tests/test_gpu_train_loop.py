@@ -88,6 +88,48 @@ def test_two_graph_data_parallel_step_equals_single_graph_step(pg):
     assert any(not torch.equal(a, c) for a, c in zip(base, comp))
 
 
+@pytest.mark.parametrize("mode", ["ddp", "fsdp2"])
+def test_checkpoint_round_trip_across_wrappers(pg, mode, tmp_path):
+    """A checkpoint written from a DDP- or FSDP2-wrapped model (full tensors, gathered by a collective for the sharded
+    case) loads into a bare Model with identical inference output, and resumes a freshly wrapped model + optimizer."""
+    from src.model.model_builder import Model
+    from src.training.utils_train import (checkpoint_states, get_optimizer, load_checkpoint, prepare_ddp_model,
+                                          prepare_fsdp2_model, save_checkpoint)
+    rank, world, gpu = pg
+    wrap = prepare_ddp_model if mode == "ddp" else prepare_fsdp2_model
+    conf = {"precision": "float32", "find_unused_parameters": False}
+    torch.manual_seed(5)
+    model = wrap(model=Model(**NANO, num_classes=80), device_id=gpu, config=conf, world_size=world, device="cuda")
+    opt, _ = get_optimizer(model, lr=1e-3, weight_decay=1e-4, patience=3, factor=0.5)
+    img = torch.randn(2, 3, 160, 160, device="cuda")
+    model.train()
+    preds, _, _ = model(img)
+    preds.float().square().mean().backward()
+    opt.step()
+    save_checkpoint(model, opt, 4, 0.25, checkpoint_dir=str(tmp_path), states=checkpoint_states(model, opt))
+    path = os.path.join(str(tmp_path), "model_epoch_4.pth")
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert all(type(v) is torch.Tensor for v in ck["model_state"].values()), "checkpoint holds sharded / wrapped tensors"
+    model.eval()
+    with torch.no_grad():
+        want = model(img)[0].float()
+    bare = Model(**NANO, num_classes=80).cuda()
+    bare.load_weights(path)
+    bare.eval()
+    with torch.no_grad():
+        got = bare(img)[0].float()
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), float((got - want).abs().max())
+    fresh = wrap(model=Model(**NANO, num_classes=80), device_id=gpu, config=conf, world_size=world, device="cuda")
+    opt2, _ = get_optimizer(fresh, lr=1e-3, weight_decay=1e-4, patience=3, factor=0.5)
+    assert load_checkpoint(fresh, opt2, path, map_location="cuda") == 4
+    fresh.eval()
+    with torch.no_grad():
+        again = fresh(img)[0].float()
+    assert torch.allclose(again, want, rtol=1e-4, atol=1e-5)
+    st = opt2.state_dict()["state"]
+    assert len(st) > 0 and all("exp_avg" in v for v in st.values())
+
+
 @pytest.mark.parametrize("group", [1, 3, 8])
 def test_runner_gradients_equal_plain_autograd(group, monkeypatch):
     """TrainStepRunner runs the conv weight gradients on a side stream that is joined lazily, several layers per

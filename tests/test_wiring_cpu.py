@@ -147,3 +147,31 @@ def test_validation_host_wiring():
     for k, v in zip(gm["thr0.5:compute_keys"], gm["thr0.5:compute_vals"].tolist()):
         assert abs(res[str(k)] - v) <= 1e-12 + 1e-7 * abs(v), (k, res[str(k)], v)
     assert m.class_tp.tolist() == gm["thr0.5:class_tp"].long().tolist()
+
+
+def test_checkpoints_load_under_any_wrapper_prefix(tmp_path):
+    """A reference-style DDP checkpoint ("module."-prefixed keys, which the reference's own Model.load_weights
+    rejects) loads into a bare Model, and load_checkpoint resumes a model + optimizer from a bare-key checkpoint"""
+    from src.model.model_builder import Model
+    from src.training.utils_train import canonical_state_dict, load_checkpoint, save_checkpoint
+    cfg = dict(csp=[False, True], depth=[1] * 6, width=[3, 16, 32, 64, 128, 256])
+    torch.manual_seed(1)
+    a, b = Model(**cfg, num_classes=8), Model(**cfg, num_classes=8)
+    ddp_style = {"module." + k: v.clone() for k, v in a.state_dict().items()}
+    assert set(canonical_state_dict(ddp_style)) == set(a.state_dict())
+    p = tmp_path / "ref_ddp.pth"
+    torch.save({"epoch": 7, "model_state": ddp_style, "val_loss": 1.0}, p)
+    b.load_weights(str(p))
+    for (k, va), vb in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(va, vb), k
+    opt_a = torch.optim.AdamW(a.parameters(), lr=1e-3)
+    for q in a.parameters():
+        q.grad = torch.ones_like(q) * 1e-3
+    opt_a.step()
+    save_checkpoint(a, opt_a, 3, 0.5, checkpoint_dir=str(tmp_path))
+    c = Model(**cfg, num_classes=8)
+    opt_c = torch.optim.AdamW(c.parameters(), lr=1e-3)
+    assert load_checkpoint(c, opt_c, str(tmp_path / "model_epoch_3.pth")) == 3
+    assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), c.state_dict().values()))
+    sa, sc = opt_a.state_dict()["state"], opt_c.state_dict()["state"]
+    assert sa.keys() == sc.keys() and all(torch.equal(sa[k]["exp_avg"], sc[k]["exp_avg"]) for k in sa)
