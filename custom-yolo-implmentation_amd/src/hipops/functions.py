@@ -37,6 +37,8 @@ FOLD_BN_FINALIZE = True     # BN scale/shift are derived in the prologue of the 
 OVERLAP_WGRAD = True        # run a conv's weight gradient on a side stream, concurrently with its data gradient
 
 
+FWD_STREAM = None           # see ConvBnAct.forward
+HEAD_TWO_STREAMS = os.environ.get("YOLO_HEAD_STREAMS", "1") == "1"
 LAZY_WGRAD_JOIN = False     # set by a caller that owns the whole backward (TrainStepRunner) and joins at its end
 # convs per cross-stream sync point in lazy mode.  Measured on preset s (img/s): per-layer fork/join 2238, 1: 2275,
 # 2: 2320, 4: 2339, 8: 2354-2368, 12: 2330, 16: 2322, 32: 2312, all at the end: 2217 (dy has left the caches by then);
@@ -160,7 +162,16 @@ class ConvBnAct(torch.autograd.Function):
     separate pass over y); the backward uses the deterministic two-level reduction."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps, out=None):
+    def forward(ctx, *args):
+        # FWD_STREAM: launch this node's kernels on another stream while autograd still sees it on the current one
+        # (its backward then runs on the current stream; see Head.forward)
+        if FWD_STREAM is not None:
+            with torch.cuda.stream(FWD_STREAM):
+                return ConvBnAct._forward(ctx, *args)
+        return ConvBnAct._forward(ctx, *args)
+
+    @staticmethod
+    def _forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps, out=None):
         T = compute_dtype(x, weight)
         cout = weight.shape[0]
         acc_f = None
@@ -276,7 +287,14 @@ class ConvBias(torch.autograd.Function):
     """Plain dense conv + bias: the head's final nn.Conv2d 1x1 (src/model/head.py:50,60)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, k, stride):
+    def forward(ctx, *args):
+        if FWD_STREAM is not None:
+            with torch.cuda.stream(FWD_STREAM):
+                return ConvBias._forward(ctx, *args)
+        return ConvBias._forward(ctx, *args)
+
+    @staticmethod
+    def _forward(ctx, x, weight, bias, k, stride):
         T = compute_dtype(x, weight)
         x = _as_nhwc(x, T)
         cout = weight.shape[0]

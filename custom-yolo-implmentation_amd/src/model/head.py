@@ -49,9 +49,26 @@ class Head(nn.Module):
         return F_.ConvBias.apply(x, last.weight, last.bias, 1, 1)
 
     def forward(self, x):
-        outs = []
-        for i in range(self.nl):
-            outs += [self._branch(self.box[i], x[i]), self._branch(self.cls[i], x[i])]
+        if self.training and x[0].is_cuda and F_.HEAD_TWO_STREAMS and torch.is_grad_enabled():
+            # forward of the class branches on the auxiliary stream, beside the box branches (one fork, one join).
+            # Only the LAUNCHES move (F_.FWD_STREAM, inside each node's forward): autograd still records the nodes
+            # on the current stream, so the backward stays single-stream -- backward nodes that autograd itself runs
+            # on a second stream crash graph capture on this stack
+            dev = x[0].device
+            cur, side = torch.cuda.current_stream(dev), F_.side_stream(dev)
+            side.wait_stream(cur)
+            F_.FWD_STREAM = side
+            try:
+                cls_outs = [self._branch(self.cls[i], x[i]) for i in range(self.nl)]
+            finally:
+                F_.FWD_STREAM = None
+            box_outs = [self._branch(self.box[i], x[i]) for i in range(self.nl)]
+            cur.wait_stream(side)
+            outs = [o for pair in zip(box_outs, cls_outs) for o in pair]
+        else:
+            outs = []
+            for i in range(self.nl):
+                outs += [self._branch(self.box[i], x[i]), self._branch(self.cls[i], x[i])]
         preds = F_.HeadPack.apply(*outs)
         shapes = tuple((int(o.shape[2]), int(o.shape[3])) for o in outs[::2])
         anchors, strides = make_anchors_cached(shapes, tuple(float(s) for s in self.stride), preds.dtype, preds.device)
