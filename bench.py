@@ -207,7 +207,8 @@ def main():
     if rank == 0 and not args.no_roofline:
         timer = KernelTimer(ops).install()
         from src.hipops import functions as F_
-        F_.OVERLAP_WGRAD = False                     # time every leaf alone (in the graph wgrad runs beside dgrad)
+        F_.OVERLAP_WGRAD = False                     # time every leaf alone (in the graph wgrad runs beside dgrad
+        two_streams, F_.HEAD_TWO_STREAMS = F_.HEAD_TWO_STREAMS, False      # and the head's class branches beside the box ones)
         try:
             torch.cuda.synchronize()
             torch.cuda._sleep(int(1.5e9))            # park the GPU so the host queues the whole step ahead:
@@ -219,6 +220,7 @@ def main():
         finally:
             timer.remove()
             F_.OVERLAP_WGRAD = True
+            F_.HEAD_TWO_STREAMS = two_streams
         groups_out = {k: dict(ms=round(v["ms"], 3), launches=v["launches"],
                               tflops=round(v["flops"] / v["ms"] / 1e9, 1) if v["flops"] else None,
                               gbs=round(v["bytes"] / v["ms"] / 1e6, 1) if v["bytes"] else None) for k, v in groups.items()}
