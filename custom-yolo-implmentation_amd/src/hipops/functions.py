@@ -425,27 +425,41 @@ class CatInto(torch.autograd.Function):
 
 
 class Chunk2(torch.autograd.Function):
-    """x.chunk(2, 1): two channel-slice views; backward re-assembles the halves (zeros where unused)."""
+    """x.chunk(2, 1): two channel-slice views; backward re-assembles the halves (zeros where unused).
+    `fanout=True` returns the second half twice (for a caller that feeds it to two consumers, C3K2: the concat and
+    the first block): autograd then delivers the two gradients separately instead of adding them first, and when the
+    gradients of both halves are neighbouring slices of one buffer (the concat's gradient) the third is accumulated
+    into that buffer in place and the buffer's head IS the result -- one launch instead of an add and two copies."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, fanout=False):
         x = _as_nhwc(x, x.dtype)
         h = x.shape[1] // 2
         ctx.shape = tuple(x.shape)
+        if fanout:
+            return x[:, :h], x[:, h:], x[:, h:]
         return x[:, :h], x[:, h:]
 
     @staticmethod
-    def backward(ctx, g0, g1):
+    def backward(ctx, g0, g1, g2=None):
         n, c, h, w = ctx.shape
-        ref = g0 if g0 is not None else g1
-        dx = ops.new_nhwc(n, c, h, w, ref.dtype, ref.device)
         half = c // 2
+        if g0 is not None and g1 is not None and g0.dtype == g1.dtype and g0.stride() == g1.stride() \
+                and ops.is_nhwc(g0) and ops.geom(g0)[4] >= c \
+                and g1.data_ptr() == g0.data_ptr() + half * g0.element_size():
+            if g2 is not None:
+                ops.copy_channels(_as_nhwc(g2, g1.dtype), g1, accumulate=True)
+            return g0.as_strided((n, c, h, w), g0.stride(), g0.storage_offset()), None
+        ref = g0 if g0 is not None else (g1 if g1 is not None else g2)
+        dx = ops.new_nhwc(n, c, h, w, ref.dtype, ref.device)
         for g, sl in ((g0, dx[:, :half]), (g1, dx[:, half:])):
             if g is None:
                 ops.copy_channels(ops.zero_(ops.new_nhwc(n, sl.shape[1], h, w, ref.dtype, ref.device)), sl)
             else:
                 ops.copy_channels(_as_nhwc(g, ref.dtype), sl)
-        return dx
+        if g2 is not None:
+            ops.copy_channels(_as_nhwc(g2, ref.dtype), dx[:, half:], accumulate=True)
+        return dx, None
 
 
 class MaxPool5(torch.autograd.Function):

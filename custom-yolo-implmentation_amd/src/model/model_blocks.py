@@ -97,9 +97,11 @@ class C3K2(nn.Module):
         # conv1 and every chained block write straight into the concat buffer conv2 reads
         h = self.conv1.conv.out_channels // 2
         buf = F_.cat_buffer(x, self.conv1.conv.weight, (2 + len(self.res_m)) * h)
-        parts = list(F_.Chunk2.apply(self.conv1(x, out=buf[:, :2 * h])))     # two views of the buffer's head
+        # two views of the buffer's head; the second half also feeds the first block (see Chunk2 on fan-out)
+        a, b, b_blk = F_.Chunk2.apply(self.conv1(x, out=buf[:, :2 * h]), True)
+        parts = [a, b]
         for i, m in enumerate(self.res_m):
-            parts.append(m(parts[-1], out=buf[:, (2 + i) * h:(3 + i) * h]))
+            parts.append(m(b_blk if i == 0 else parts[-1], out=buf[:, (2 + i) * h:(3 + i) * h]))
         return self.conv2(F_.CatInto.apply(buf, *parts))
 
 
@@ -166,7 +168,7 @@ class PSA(nn.Module):
         self.res_m = nn.Sequential(*(PSABlock(ch // 2, ch // 128) for _ in range(n)))
 
     def forward(self, x):
-        a, b = F_.Chunk2.apply(self.conv1(x))
+        a, b = F_.Chunk2.apply(self.conv1(x), False)
         return self.conv2(F_.Cat.apply(a, self.res_m(b)))
 
 
