@@ -155,6 +155,29 @@ class BnArena:
         return 2 * sum(ops.BN_REPL * 2 * c for c in channels)      # forward statistics + backward sums per layer
 
 
+class ResLink:
+    """Shared by the two convs of x + conv2(conv1(x)): conv2's backward leaves the residual gradient here and conv1's
+    data gradient is ADDED to it in its kernel epilogue, instead of autograd summing two tensors with one more pass
+    over them.  Safe only if nothing else consumes x between the two: Residual wraps its input in `Alias`, whose only
+    consumers are those two convs."""
+    __slots__ = ("dres",)
+
+    def __init__(self):
+        self.dres = None
+
+
+class Alias(torch.autograd.Function):
+    """The same tensor under a new autograd node: consumers of the alias are the alias' only consumers."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _fresh(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class ConvBnAct(torch.autograd.Function):
     """act(BN(conv(x))) (+ residual).  Reference: Conv.forward, src/model/model_blocks.py:31-34; the
     residual adds of Residual/PSABlock (:62, :223-224) ride in the same epilogue.
@@ -171,7 +194,9 @@ class ConvBnAct(torch.autograd.Function):
         return ConvBnAct._forward(ctx, *args)
 
     @staticmethod
-    def _forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps, out=None):
+    def _forward(ctx, x, weight, gamma, beta, res, bufs, k, stride, depthwise, act, training, momentum, eps, out=None,
+                 res_link=None):
+        ctx.res_link = res_link
         T = compute_dtype(x, weight)
         cout = weight.shape[0]
         acc_f = None
@@ -268,7 +293,14 @@ class ConvBnAct(torch.autograd.Function):
                 else:
                     dw = ops.dw_wgrad(x, dy).to(weight.dtype)
         else:
-            dgrad = lambda: ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride)
+            link = ctx.res_link if not has_res else None
+            into = link.dres if link is not None else None          # the residual gradient conv2's backward left
+            if into is not None and (tuple(into.shape) != (n, cin, h, w) or into.dtype != T or not ops.is_nhwc(into)):
+                into = None
+
+            def dgrad():
+                r = ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride, acc_into=into)
+                return None if into is not None else r      # already inside the gradient autograd holds for x
             if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
                 dx, dw = _wgrad_overlapped(x, dy, k, stride, weight.dtype, dgrad)
             elif ctx.needs_input_grad[0]:
@@ -280,7 +312,9 @@ class ConvBnAct(torch.autograd.Function):
         else:
             dgamma = dbeta = None
         dres = dout if (has_res and ctx.needs_input_grad[4]) else None
-        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        if has_res and ctx.res_link is not None:
+            ctx.res_link.dres = dres
+        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class ConvBias(torch.autograd.Function):

@@ -251,11 +251,18 @@ def bn_act_bwd_train(dout, y, scale, shift, mean, invstd, gamma, act, acc):
     return dy, dgamma, dbeta
 
 
-def conv_dgrad(dy, wb, cin, h, w, k, stride):
+def conv_dgrad(dy, wb, cin, h, w, k, stride, acc_into=None):
+    """Data gradient; with `acc_into` (an NHWC tensor or channel-slice view of the input's shape) it is ADDED to that
+    tensor in the kernel epilogue instead of being written to a new one (returns acc_into)."""
     n, cout, oh, ow, lddy = geom(dy)
-    dx = new_nhwc(n, cin, h, w, dy.dtype, dy.device)
-    lib.call("yolo_conv2d_dgrad", _p(dy), lddy, _p(wb), _p(dx), cin, n, h, w, cin, oh, ow, cout, k, stride, 0,
-             dt(dy), ALGO, _stream(dy))
+    if acc_into is None:
+        dx, accumulate = new_nhwc(n, cin, h, w, dy.dtype, dy.device), 0
+    else:
+        if tuple(acc_into.shape) != (n, cin, h, w) or acc_into.dtype != dy.dtype:
+            raise RuntimeError("conv_dgrad: acc_into does not match the input gradient's shape / dtype")
+        dx, accumulate = acc_into, 1
+    lib.call("yolo_conv2d_dgrad", _p(dy), lddy, _p(wb), _p(dx), geom(dx)[4], n, h, w, cin, oh, ow, cout, k, stride,
+             accumulate, dt(dy), ALGO, _stream(dy))
     return dx
 
 

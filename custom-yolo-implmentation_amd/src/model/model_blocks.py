@@ -37,13 +37,14 @@ class Conv(nn.Module):
         self._k, self._s, self._dw, self._act = k, s, g != 1, _act_code(activation)
         self._count_batches = True      # a parent Model bumps all counters in one multi-tensor op instead
 
-    def forward(self, x, residual=None, out=None):
-        """`out`: optional destination view (a channel slice of the consumer's concat buffer, F_.cat_buffer)."""
+    def forward(self, x, residual=None, out=None, res_link=None):
+        """`out`: optional destination view (a channel slice of the consumer's concat buffer, F_.cat_buffer).
+        `res_link`: see F_.ResLink (Residual)."""
         n = self.norm
         if self.training and self._count_batches:
             n.num_batches_tracked.add_(1)
         return F_.ConvBnAct.apply(x, self.conv.weight, n.weight, n.bias, residual, (n.running_mean, n.running_var),
-                                  self._k, self._s, self._dw, self._act, self.training, n.momentum, n.eps, out)
+                                  self._k, self._s, self._dw, self._act, self.training, n.momentum, n.eps, out, res_link)
 
     def fuse_forward(self, x, residual=None, out=None):
         return F_.fused_conv_act(x, self.conv.weight, self.conv.bias, self._k, self._s, self._dw, self._act, residual, out)
@@ -59,7 +60,12 @@ class Residual(nn.Module):
         self.conv2 = Conv(mid, ch, nn.SiLU(), k=3, p=1)
 
     def forward(self, x, out=None):
-        return self.conv2(self.conv1(x), x, out=out)
+        if not (self.training and torch.is_grad_enabled()):
+            return self.conv2(self.conv1(x), x, out=out)
+        # conv1's data gradient is accumulated into the residual gradient by its own kernel (F_.ResLink); the alias
+        # makes sure the two convs are the only consumers of what they see as x
+        xp, link = F_.Alias.apply(x), F_.ResLink()
+        return self.conv2(self.conv1(xp, res_link=link), xp, out=out, res_link=link)
 
 
 class C3K(nn.Module):
