@@ -35,10 +35,8 @@ def _f32(t):
 _SIDE = {}
 FOLD_BN_FINALIZE = True     # BN scale/shift are derived in the prologue of the activation kernel (no finalize launch)
 OVERLAP_WGRAD = True        # run a conv's weight gradient on a side stream, concurrently with its data gradient
-
-
 FWD_STREAM = None           # see ConvBnAct.forward
-HEAD_TWO_STREAMS = os.environ.get("YOLO_HEAD_STREAMS", "1") == "1"
+HEAD_TWO_STREAMS = os.environ.get("YOLO_HEAD_STREAMS", "1") == "1"       # Head.forward; 0 for A/B runs
 LAZY_WGRAD_JOIN = False     # set by a caller that owns the whole backward (TrainStepRunner) and joins at its end
 # convs per cross-stream sync point in lazy mode.  Measured on preset s (img/s): per-layer fork/join 2238, 1: 2275,
 # 2: 2320, 4: 2339, 8: 2354-2368, 12: 2330, 16: 2322, 32: 2312, all at the end: 2217 (dy has left the caches by then);
@@ -75,9 +73,7 @@ def defer_to_side(dev, keepalive, fn):
     inputs until the join after it ran.  Otherwise return False (the caller runs it inline)."""
     if not (LAZY_WGRAD_JOIN and OVERLAP_WGRAD and dev.type == "cuda"):
         return False
-    side = _SIDE.get(dev)
-    if side is None:
-        side = _SIDE[dev] = torch.cuda.Stream(dev)
+    side = side_stream(dev)
     q = _QUEUED.setdefault(dev, [])
     q.append((keepalive, fn))
     if len(q) >= WGRAD_GROUP:
@@ -96,10 +92,7 @@ def _wgrad_overlapped(x, dy, k, stride, w_dtype, dgrad_fn):
     if not (OVERLAP_WGRAD and x.is_cuda):
         return dgrad_fn(), ops.conv_wgrad(x, dy, k, stride, w_dtype)
     dev = x.device
-    cur = torch.cuda.current_stream(dev)
-    side = _SIDE.get(dev)
-    if side is None:
-        side = _SIDE[dev] = torch.cuda.Stream(dev)
+    cur, side = torch.cuda.current_stream(dev), side_stream(dev)
     if LAZY_WGRAD_JOIN:
         dw = torch.empty((dy.shape[1], x.shape[1], k, k), dtype=w_dtype, device=dev)
         fn = lambda: ops.conv_wgrad(x, dy, k, stride, dw.dtype, out=dw)
