@@ -25,6 +25,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PRESET_S = dict(csp=[False, True], depth=[1] * 6, width=[3, 32, 64, 128, 256, 512])
+PRESETS = {"s": PRESET_S,                                                              # the headline workload
+           "n": dict(csp=[False, True], depth=[1] * 6, width=[3, 16, 32, 64, 128, 256]),
+           "l": dict(csp=[True, True], depth=[2] * 6, width=[3, 64, 128, 256, 512, 512]),
+           "x": dict(csp=[True, True], depth=[2] * 6, width=[3, 96, 192, 384, 768, 768])}
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -135,6 +139,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE config 2/3: 32)")
     ap.add_argument("--res", type=int, default=640)
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="s", help="other presets: extra data points, not the metric")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -164,7 +169,7 @@ def main():
 
     nc = 80
     torch.manual_seed(0)                      # identical initial weights on every rank (DDP broadcasts rank 0's)
-    model = Model(**PRESET_S, num_classes=nc).to(dev).train()
+    model = Model(**PRESETS[args.preset], num_classes=nc).to(dev).train()
     if world > 1:
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
@@ -262,7 +267,7 @@ def main():
         out = dict(metric="images/sec (640x640 bf16)", value=round(gb * args.steps / dt, 2), unit="images/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
-                   config=dict(workload=f"preset s (width 32..512, depth 1) {args.res}x{args.res} train step "
+                   config=dict(workload=f"preset {args.preset} (width {PRESETS[args.preset]['width'][1]}..{PRESETS[args.preset]['width'][5]}, depth {PRESETS[args.preset]['depth'][0]}) {args.res}x{args.res} train step "
                                         f"(fwd+DFL/QFL loss+bwd+grad sync+AdamW), COCO-80 synthetic, {args.batch} img/GPU",
                                global_batch=gb, parallelism=f"dp{world}", hip_graph=runner.graph is not None,
                                optimizer_in_graph=runner.opt_in_graph, final_loss=round(final_loss, 5)),
