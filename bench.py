@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE config 2/3: 32)")
     ap.add_argument("--res", type=int, default=640)
     ap.add_argument("--preset", choices=sorted(PRESETS), default="s", help="other presets: extra data points, not the metric")
+    ap.add_argument("--precision", choices=["bfloat16", "float16", "float32"], default="bfloat16")
+    ap.add_argument("--nc", type=int, default=80)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -167,7 +169,7 @@ def main():
     from src.model.model_builder import Model
     from src.training.graph_step import TrainStepRunner
 
-    nc = 80
+    nc = args.nc
     torch.manual_seed(0)                      # identical initial weights on every rank (DDP broadcasts rank 0's)
     model = Model(**PRESETS[args.preset], num_classes=nc).to(dev).train()
     if world > 1:
@@ -183,7 +185,7 @@ def main():
         opt = HipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
     img, gts = synthetic_batch(args.batch, args.res, nc, 1234 + rank, dev)
     packed = PackedTargets(gts, dev)
-    runner = TrainStepRunner(model, crit, opt, "bfloat16", use_graph=not args.no_graph,
+    runner = TrainStepRunner(model, crit, opt, args.precision, use_graph=not args.no_graph,
                              grad_comm_dtype=(None if os.environ.get("BENCH_COMM_DTYPE") == "fp32" else torch.bfloat16)
                              if world > 1 else None)
     runner.capture(img, packed)
@@ -266,7 +268,7 @@ def main():
         gb = args.batch * world
         out = dict(metric="images/sec (640x640 bf16)", value=round(gb * args.steps / dt, 2), unit="images/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype={"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.precision], data="synthetic",
                    config=dict(workload=f"preset {args.preset} (width {PRESETS[args.preset]['width'][1]}..{PRESETS[args.preset]['width'][5]}, depth {PRESETS[args.preset]['depth'][0]}) {args.res}x{args.res} train step "
                                         f"(fwd+DFL/QFL loss+bwd+grad sync+AdamW), COCO-80 synthetic, {args.batch} img/GPU",
                                global_batch=gb, parallelism=f"dp{world}", hip_graph=runner.graph is not None,
