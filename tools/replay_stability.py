@@ -2,7 +2,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "custom-yolo-implmentation_amd"))
 import torch
+from src.hipops import functions as F_
 from src.model.model_builder import Model
+F_.HEAD_TWO_STREAMS = False      # the per-layer hooks below read each output on the current stream right after its module
 from src.model.model_blocks import Conv
 NANO = dict(csp=[False, True], depth=[1] * 6, width=[3, 16, 32, 64, 128, 256])
 torch.manual_seed(0)
