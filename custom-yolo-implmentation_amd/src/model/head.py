@@ -49,7 +49,8 @@ class Head(nn.Module):
         return F_.ConvBias.apply(x, last.weight, last.bias, 1, 1)
 
     def forward(self, x):
-        if self.training and x[0].is_cuda and F_.HEAD_TWO_STREAMS and torch.is_grad_enabled():
+        hooked = any(m._forward_hooks or m._forward_pre_hooks for m in self.cls.modules())    # a user hook would read a
+        if self.training and x[0].is_cuda and F_.HEAD_TWO_STREAMS and torch.is_grad_enabled() and not hooked:    # side-stream tensor unsynchronised
             # forward of the class branches on the auxiliary stream, beside the box branches (one fork, one join).
             # Only the LAUNCHES move (F_.FWD_STREAM, inside each node's forward): autograd still records the nodes
             # on the current stream, so the backward stays single-stream -- backward nodes that autograd itself runs
