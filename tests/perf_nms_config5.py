@@ -1,7 +1,7 @@
 """Inference tail on BASELINE config 5 shapes (preset l @1280: M = 33600 anchors, 80 classes, fp16): head decode +
 class-aware NMS on the device vs the oracle's restatement of the reference's Python / torchvision path on the host."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file lives in tests/)
 sys.path.insert(0, os.path.join(ROOT, "custom-yolo-implmentation_amd"))
 sys.path.insert(0, ROOT)
 import torch

@@ -1,7 +1,7 @@
 """Validation path on one 32-image batch of preset-s shapes: device select + match vs the per-image
 Python loops of the reference's algorithm (oracle restatement) on the host.  Run on the GPU box."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file lives in tests/)
 sys.path.insert(0, os.path.join(ROOT, "custom-yolo-implmentation_amd"))
 sys.path.insert(0, ROOT)
 import torch
