@@ -14,6 +14,12 @@ int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const vo
 int mfma_wgrad2_slabs(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k);
 int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* part, void* dw_oihw, int dw_dtype, int Kpad,
                        int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
+int f32_conv_eligible(const ConvGeom& g, const void* src, const void* wm, const void* dst);
+int f32_conv_launch(const ConvGeom& g, const float* src, const float* wm, const float* bias, float* dst, int accumulate,
+                    hipStream_t st);
+int f32_wgrad_eligible(const void* x, int ldx, const void* dy, int ldy, int Cin, int Cout);
+int f32_wgrad_launch(const float* x, int ldx, const float* dy, int ldy, float* dwp, int Kpad, int N, int H, int W, int Cin,
+                     int OH, int OW, int Cout, int k, int stride, hipStream_t st);
 int mfma_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* dwp, int Kpad, int N, int H, int W,
                       int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
 
@@ -273,6 +279,8 @@ int launch_generic(const ConvGeom& g, const void* src, const void* wm, const flo
                    int dtype, hipStream_t st) {
     long total = (long)g.N * g.Hg * g.Wg * g.Cd;
     if (total == 0) return YOLO_OK;
+    if (dtype == YOLO_F32 && f32_conv_eligible(g, src, wm, dst))        // LDS-tiled fp32 kernel (conv_f32.hip)
+        return f32_conv_launch(g, (const float*)src, (const float*)wm, bias, (float*)dst, accumulate, st);
     YOLO_DISPATCH_T(dtype, {
         bool ok = vecok<T>(src, g.lds, g.Cs) && vecok<T>(wm, g.Kpad, g.Cs);
         if (ok) {
@@ -456,6 +464,8 @@ int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws
     if (rc) return rc;
     if (path == 3) {
         rc = mfma_wgrad_launch(x, ldx, dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, dtype, st);
+    } else if (dtype == YOLO_F32 && f32_wgrad_eligible(x, ldx, dy, ldy, Cin, Cout)) {
+        rc = f32_wgrad_launch((const float*)x, ldx, (const float*)dy, ldy, dwp, Kpad, N, H, W, Cin, OH, OW, Cout, k, stride, st);
     } else {
         long nrows = (long)N * OH;
         long elems = (long)Cout * K;
