@@ -55,11 +55,14 @@ __global__ void k_decode(LossDims d, const T* __restrict__ preds, const T* __res
     pbox[i] = make_float4((x1 + x2) / 2.f, (y1 + y2) / 2.f, x2 - x1, y2 - y1);
 }
 
+// grid = G rows of the gt buffer; rows past the live count gt_off[N] (a buffer with spare capacity, refilled between
+// replays of a captured step) do nothing
 __global__ void k_assign(int A, const float4* __restrict__ pbox, const float* __restrict__ gt,
-                         const int* __restrict__ gt_img, int* __restrict__ idx) {
+                         const int* __restrict__ gt_img, const int* __restrict__ gt_off, int N, int* __restrict__ idx) {
     __shared__ float sd[4];
     __shared__ int si[4];
     const int j = blockIdx.x;
+    if (j >= gt_off[N]) return;
     const float gx = gt[j * 5 + 0], gy = gt[j * 5 + 1];
     const float4* pb = pbox + (long)gt_img[j] * A;
     const float an = __fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy));
@@ -290,7 +293,8 @@ size_t yolo_loss_workspace_bytes(int N, int A, int G) {
     return b;
 }
 
-// gt: fp32 [G][5] (cx,cy,w,h,cls, pixels) grouped by image; gt_off: int32 [N+1]; gt_img: int32 [G].
+// gt: fp32 [G][5] (cx,cy,w,h,cls, pixels) grouped by image; gt_off: int32 [N+1]; gt_img: int32 [G].  G is the number of
+// ROWS of gt / gt_img; the live count is gt_off[N] <= G, read on the device (a captured step refills the buffers).
 // dpreds may be null (validation).  out: fp32[3] = {total, mean_dfl ("box_loss"), mean_cls}.
 int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A,
                       const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl,
@@ -310,7 +314,7 @@ int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* stride
     YOLO_DISPATCH_T(dtype, {
         hipLaunchKernelGGL((k_decode<T>), dim3(ceil_div(NA, 256)), dim3(256), 0, st, d, (const T*)preds,
                            (const T*)anchors, (const T*)strides, pbox);
-        if (G > 0) hipLaunchKernelGGL(k_assign, dim3(G), dim3(256), 0, st, A, pbox, gt, gt_img, idx);
+        if (G > 0) hipLaunchKernelGGL(k_assign, dim3(G), dim3(256), 0, st, A, pbox, gt, gt_img, gt_off, N, idx);
         constexpr int VV = vec_of<T>::N;
         bool vec = (A % VV == 0) && ((uintptr_t)preds % 16 == 0) && (!dpreds || (uintptr_t)dpreds % 16 == 0);
         int nblk = (int)((elems / (vec ? VV : 1) + 255) / 256);

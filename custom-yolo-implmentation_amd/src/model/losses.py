@@ -30,6 +30,50 @@ class PackedTargets:
         return self.gt, self.gt_off, self.gt_img, self.n_gt
 
 
+class StaticTargets:
+    """PackedTargets with fixed-capacity device buffers that `load()` refills in place: the form a captured training
+    step needs (the kernels read the live count from gt_off[N] on the device; rows past it are ignored)."""
+
+    def __init__(self, n_img, capacity, device):
+        self.n_img, self.capacity = n_img, capacity
+        self.gt = torch.zeros((capacity, 5), dtype=torch.float32, device=device)
+        self.gt_off = torch.zeros(n_img + 1, dtype=torch.int32, device=device)
+        self.gt_img = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self._h_gt = torch.zeros((capacity, 5), dtype=torch.float32).pin_memory()
+        self._h_off = torch.zeros(n_img + 1, dtype=torch.int32).pin_memory()
+        self._h_img = torch.zeros(capacity, dtype=torch.int32).pin_memory()
+        self.n_gt, self._uploaded = 0, None
+
+    def load(self, gt_boxes_list):
+        """Refill from a batch's list of (Mi, 5) tensors; False (nothing changed) if they do not fit."""
+        if len(gt_boxes_list) != self.n_img:
+            return False
+        counts = [int(g.shape[0]) if g.numel() > 0 else 0 for g in gt_boxes_list]
+        total = sum(counts)
+        if total > self.capacity:
+            return False
+        if self._uploaded is not None:
+            self._uploaded.synchronize()                # the previous upload has left the pinned buffers
+        off = 0
+        self._h_off[0] = 0
+        for i, (g, c) in enumerate(zip(gt_boxes_list, counts)):
+            if c:
+                self._h_gt[off:off + c].copy_(g.reshape(-1, 5).to(dtype=torch.float32, device="cpu"))
+                self._h_img[off:off + c] = i
+            off += c
+            self._h_off[i + 1] = off
+        self.gt.copy_(self._h_gt, non_blocking=True)
+        self.gt_off.copy_(self._h_off, non_blocking=True)
+        self.gt_img.copy_(self._h_img, non_blocking=True)
+        self._uploaded = torch.cuda.Event()
+        self._uploaded.record(torch.cuda.current_stream(self.gt.device))
+        self.n_gt = total
+        return True
+
+    def as_tuple(self):
+        return self.gt, self.gt_off, self.gt_img, self.capacity
+
+
 class LazyLossDict(dict):
     """{"total_loss","box_loss","cls_loss": float}.  The three scalars stay on the device until first
     read and then arrive with ONE device->host copy (the reference does three .item() syncs, :278-280)."""
@@ -96,7 +140,8 @@ class YoloDFLQFLoss(nn.Module):
     def forward(self, preds, gt_boxes_list, anchors, strides):
         """preds (N, 64+nc, M); gt_boxes_list: N tensors (Mi,5) [cx,cy,w,h,cls] in pixels, or a
         PackedTargets; anchors (2,M); strides (1,M) -> (loss 0-d tensor with grad, dict of 3 floats)."""
-        packed = gt_boxes_list if isinstance(gt_boxes_list, PackedTargets) else PackedTargets(gt_boxes_list, preds.device)
+        packed = gt_boxes_list if isinstance(gt_boxes_list, (PackedTargets, StaticTargets)) \
+            else PackedTargets(gt_boxes_list, preds.device)
         if packed.n_img != preds.shape[0]:
             raise ValueError("one GT tensor per image is required")
         total, scalars = F_.DflQflLoss.apply(preds, anchors, strides, packed.as_tuple(), self.num_classes,

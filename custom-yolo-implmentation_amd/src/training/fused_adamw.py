@@ -70,7 +70,19 @@ class HipAdamW(torch.optim.Optimizer):
         for dev_t, host_t in self._pending:
             dev_t.copy_(host_t)
         self._pending = []
+        for plan in self._plans.values():               # kept for restore_capture()
+            if plan["host"] is not None:
+                plan["cap_host"], plan["cap_ptrs"] = plan["host"].clone(), plan["ptrs"]
         self.sync_hyper()
+
+    def restore_capture(self):
+        """After an EAGER step() between replays (its gradients live elsewhere, so it rebuilt the job table the captured
+        launch reads): put the captured table back."""
+        for plan in self._plans.values():
+            if plan.get("cap_host") is not None and plan["ptrs"] != plan["cap_ptrs"]:
+                plan["host"].copy_(plan["cap_host"])
+                plan["jobs_dev"].copy_(plan["host"])
+                plan["ptrs"] = plan["cap_ptrs"]
 
     # ------------------------------------------------------------------------------------------ step
     @torch.no_grad()

@@ -93,7 +93,8 @@ class TrainStepRunner:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._eager_step(images, packed)
+                _, ld = self._eager_step(images, packed)
+                self.warm_scalars = ld._scalars         # the loss scalars of the last warm-up step (a real step)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         capturable = all(g.get("capturable", False) for g in self.optimizer.param_groups)
@@ -143,6 +144,29 @@ class TrainStepRunner:
         else:                                                 # gloo has no AVG
             dist.all_reduce(self.flat)
             self.flat.div_(self.world)
+
+    def capture_for_batches(self, images, gt_boxes_list, boxes_per_image=128, warmup=3):
+        """Capture on buffers that `step_batch` refills: a static image tensor and fixed-capacity target buffers
+        (`StaticTargets`, capacity = boxes_per_image x batch size).  The data loader must keep batch size and
+        resolution fixed (the reference's does: drop_last)."""
+        from src.model.losses import StaticTargets
+        self.static_images = images.detach().clone()
+        self.static_targets = StaticTargets(len(gt_boxes_list), boxes_per_image * len(gt_boxes_list), images.device)
+        if not self.static_targets.load(gt_boxes_list):
+            raise RuntimeError("capture_for_batches: the first batch does not fit the target capacity")
+        return self.capture(self.static_images, self.static_targets, warmup=warmup)
+
+    def step_batch(self, images, gt_boxes_list):
+        """One optimizer step on a NEW batch of the captured shape: refill the static buffers, replay.  Returns the
+        device loss tensor, or None if the batch does not fit (other batch size / resolution, more boxes than the
+        capacity): the caller then runs that batch eagerly."""
+        st = getattr(self, "static_images", None)
+        if st is None or images.shape != st.shape or images.dtype != st.dtype:
+            return None
+        if not self.static_targets.load(gt_boxes_list):
+            return None
+        st.copy_(images, non_blocking=True)
+        return self.step()
 
     def step(self):
         """One optimizer step on the static batch; returns the (device) loss tensor of that step."""

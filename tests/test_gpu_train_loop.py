@@ -19,8 +19,10 @@ def pg():
     cleanup_distribute_mode()
 
 
-@pytest.mark.parametrize("mode,precision", [("ddp", "bfloat16"), ("ddp", "float32"), ("ddp", "float16"), ("fsdp2", "bfloat16")])
-def test_train_one_epoch_like_the_script(pg, mode, precision, tmp_path):
+@pytest.mark.parametrize("mode,precision,captured", [("ddp", "bfloat16", False), ("ddp", "float32", False),
+                                                     ("ddp", "float16", False), ("fsdp2", "bfloat16", False),
+                                                     ("ddp", "bfloat16", True), ("ddp", "float32", True)])
+def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path):
     from src.data.data_loader import get_data_loaders
     from src.model.losses import YoloDFLQFLoss
     from src.model.model_builder import Model
@@ -30,15 +32,19 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, tmp_path):
     torch.manual_seed(0)
     model = Model(**NANO, num_classes=80)
     wrap = prepare_ddp_model if mode == "ddp" else prepare_fsdp2_model
-    model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False},
-                 world_size=world, device="cuda")
+    if captured:        # the captured loop is for an unwrapped model (single process): see CapturedTraining
+        model = model.cuda()
+    else:
+        model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False},
+                     world_size=world, device="cuda")
     tr, va = get_data_loaders("/nonexistent/train", "/nonexistent/val", "", "", batch_size=4, is_test=True, device="cuda",
                               num_classes=80, res=160)
     opt, sched = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
     before = [p.detach().float().clone() for p in model.parameters()][:3]
     train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched,
           criterion=YoloDFLQFLoss(num_classes=80), initial_epoch=0, num_epochs=1, device=gpu, num_classes=80, rank=rank,
-          checkpoint_dir=str(tmp_path), distributed_mode=mode, precision=precision, conf_threshold=0.01)
+          checkpoint_dir=str(tmp_path), distributed_mode=mode, precision=precision, conf_threshold=0.01,
+          captured_step=captured)
     after = [p.detach().float() for p in model.parameters()][:3]
     assert any(not torch.equal(a, b) for a, b in zip(before, after)), "parameters did not move"
     assert all(torch.isfinite(a).all() for a in after)
@@ -188,6 +194,57 @@ def test_runner_gradients_equal_plain_autograd(group, monkeypatch):
     torch.cuda.synchronize()
     got = grads()
     check(plain(img), got, "graph replay")
+
+
+def test_captured_step_on_new_batches_equals_eager_steps():
+    """TrainStepRunner.step_batch refills the static image / target buffers (different images, different numbers of
+    boxes per image, an image without boxes, fewer boxes than at capture) and replays: after three such steps the
+    weights equal those of a twin model stepped eagerly on the same batches (fp32, plain AdamW semantics)."""
+    from src.model.losses import YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.fused_adamw import HipAdamW
+    from src.training.graph_step import TrainStepRunner
+    g = torch.Generator().manual_seed(21)
+
+    def batch(counts):
+        img = torch.randn(len(counts), 3, 160, 160, generator=g).cuda()
+        gts = [torch.cat([torch.rand(c, 2, generator=g) * 160, torch.rand(c, 2, generator=g) * 60 + 8,
+                          torch.randint(0, 80, (c, 1), generator=g).float()], 1) for c in counts]
+        return img, gts
+
+    batches = [batch([3, 5]), batch([1, 0]), batch([7, 2]), batch([2, 2])]
+    torch.manual_seed(0)
+    a = Model(**NANO, num_classes=80).cuda().train()
+    b = Model(**NANO, num_classes=80).cuda().train()
+    b.load_state_dict(a.state_dict())
+    start = [p.detach().clone() for p in a.parameters()]
+    crit = YoloDFLQFLoss(num_classes=80)
+    oa, ob = HipAdamW(a.parameters(), lr=1e-4, weight_decay=1e-2), HipAdamW(b.parameters(), lr=1e-4, weight_decay=1e-2)
+    ra = TrainStepRunner(a, crit, oa, "float32", use_graph=True)
+    ra.capture_for_batches(*batches[0], boxes_per_image=8, warmup=1)        # capture steps on batch 0 (warm-up + none)
+    rb = TrainStepRunner(b, crit, ob, "float32", use_graph=False)
+    for _ in range(1):                                                      # the same eager warm-up steps on the twin
+        rb._eager_step(batches[0][0], [t.cuda() for t in batches[0][1]])
+    losses = []
+    for img, gts in batches[1:]:
+        la = ra.step_batch(img, gts)
+        assert la is not None
+        lb, _ = rb._eager_step(img, [t.cuda() for t in gts])
+        losses.append((float(la), float(lb)))
+    torch.cuda.synchronize()
+    # the first new batch sees identical weights: sharp; later ones see weights that Adam's sign-like update has moved
+    # apart by last-bit gradient noise (and the loss's anchor assignment is discrete)
+    for k, (x, y) in enumerate(losses):
+        assert abs(x - y) <= (1e-4 if k == 0 else 5e-3) * abs(y) + 1e-5, losses
+    # Adam's update is sign-like (lr * m / sqrt(v)): last-bit noise of the atomically summed statistics moves a weight
+    # with a near-zero gradient by up to ~lr per step, so the weights are compared at a few lr; the per-step losses
+    # above, which see the updated weights, are the sharp check
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert float((p - q).abs().max()) <= 4e-4, (n, float((p - q).abs().max()))
+    moved = max(float((p - q0).abs().max()) for p, q0 in zip(a.parameters(), start))
+    assert moved > 2e-4, "the captured steps did not update the weights"
+    assert ra.step_batch(*batch([9, 9])) is None                            # 18 boxes > capacity 16: caller falls back
+    assert ra.step_batch(torch.randn(2, 3, 128, 128).cuda(), batches[1][1]) is None
 
 
 def test_graph_replays_reproduce_the_eager_forward():
