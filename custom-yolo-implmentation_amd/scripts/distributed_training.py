@@ -67,6 +67,10 @@ def main(args):
         use_wandb = use_wandb and run is not None
 
         model = Model(**model_cfg["config"], num_classes=model_cfg["num_classes"])
+        captured = bool(tr_cfg.get("captured_step", False)) and args.mode == "ddp" and args.device == "cuda" \
+            and args.precision in ("bfloat16", "float32")       # optional key: the step as one replayed hipGraph
+        if captured:
+            tr_cfg[args.mode]["captured_step"] = True
         model = WRAP[args.mode](model=model, device_id=gpu, config=tr_cfg[args.mode], world_size=world_size, device=args.device)
         print(f"[INFO] {args.mode.upper()} model initialzed")
         model = model.to(args.device)
@@ -90,7 +94,7 @@ def main(args):
               num_classes=model_cfg["num_classes"], rank=rank, use_wandb=use_wandb, wandb_instance=run,
               log_interval=tr_cfg.get("log_interval", 10), checkpoint_dir=ckpt_dir,
               iou_threshold=tr_cfg.get("iou_threshold", 0.5), conf_threshold=tr_cfg.get("conf_threshold", 0.25),
-              distributed_mode=args.mode, precision=args.precision)
+              distributed_mode=args.mode, precision=args.precision, captured_step=captured)
     finally:
         if run is not None:
             import wandb

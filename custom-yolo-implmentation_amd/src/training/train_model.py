@@ -85,8 +85,10 @@ class CapturedTraining:
                 restore()
             self.dirty = False
         if self.runner.step_batch(images, boxes) is None:
+            # does not fit the captured buffers: the runner's eager step (it averages gradients across ranks too)
             self.dirty = True
-            return None
+            _, ld = self.runner._eager_step(images, [b.to(images.device) for b in boxes])
+            return ld
         return LazyLossDict(self.runner.scalars)
 
 

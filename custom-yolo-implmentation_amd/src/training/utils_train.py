@@ -110,9 +110,19 @@ def _pin_device(device: str, device_id: int, world_size: int):
 
 def prepare_ddp_model(model: nn.Module, device_id: int, config: Dict[str, Union[str, int]], world_size: int,
                       device: str) -> nn.Module:
-    """DistributedDataParallel: bucketed gradient all-reduce overlapped with backward (reference :167-192)."""
+    """DistributedDataParallel: bucketed gradient all-reduce overlapped with backward (reference :167-192).
+    `config["captured_step"]` (opt-in, CUDA only): the model is returned UNWRAPPED after the wrapper's one-time work --
+    parameters and buffers broadcast from rank 0 -- because `train(..., captured_step=True)` then steps it through
+    `TrainStepRunner`, which averages the gradients itself with one flat all-reduce per step (same mean-over-ranks
+    semantics); the backward of a wrapped module cannot be captured on this stack."""
     _pin_device(device, device_id, world_size)
     model = model.to(device_id if device == "cuda" else device)
+    if config and config.get("captured_step") and device == "cuda":
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, 0)
+        return model
     unused = bool(config.get("find_unused_parameters", False)) if config else False
     return DDP(model, device_ids=[device_id] if device == "cuda" else None, find_unused_parameters=unused)
 
