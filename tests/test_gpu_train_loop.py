@@ -243,8 +243,21 @@ def test_captured_step_on_new_batches_equals_eager_steps():
         assert float((p - q).abs().max()) <= 4e-4, (n, float((p - q).abs().max()))
     moved = max(float((p - q0).abs().max()) for p, q0 in zip(a.parameters(), start))
     assert moved > 2e-4, "the captured steps did not update the weights"
-    assert ra.step_batch(*batch([9, 9])) is None                            # 18 boxes > capacity 16: caller falls back
+    big = batch([9, 9])
+    assert ra.step_batch(*big) is None                                      # 18 boxes > capacity 16: caller falls back
     assert ra.step_batch(torch.randn(2, 3, 128, 128).cuda(), batches[1][1]) is None
+    # the fallback is an EAGER optimizer step (new gradient tensors: HipAdamW rebuilds the job table the captured
+    # launch reads); restore_capture() must put the captured table back before the next replay
+    ra._eager_step(big[0], [t.cuda() for t in big[1]])
+    rb._eager_step(big[0], [t.cuda() for t in big[1]])
+    oa.restore_capture()
+    last = batch([4, 1])
+    la = ra.step_batch(*last)
+    lb, _ = rb._eager_step(last[0], [t.cuda() for t in last[1]])
+    torch.cuda.synchronize()
+    assert la is not None and abs(float(la) - float(lb)) <= 5e-3 * abs(float(lb)) + 1e-5, (float(la), float(lb))
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.isfinite(p).all() and float((p - q).abs().max()) <= 8e-4, (n, float((p - q).abs().max()))
 
 
 def test_graph_replays_reproduce_the_eager_forward():
