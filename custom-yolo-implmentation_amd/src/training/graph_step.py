@@ -10,6 +10,7 @@ graph 1 = forward + loss + backward + "pack all gradients into the flat communic
 copy, bf16-compressed if asked), then `all_reduce(AVG)` on the flat buffer, then graph 2 = "unpack into the
 gradients" + the (capturable) optimizer step -- a dozen launches per step from the host instead of ~300.
 """
+import gc
 import os
 
 import torch
@@ -101,6 +102,20 @@ class TrainStepRunner:
         want_opt = not self.comm and capturable
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
+        # No garbage collection while capturing: a collected object that owns pinned host memory (an optimizer's job
+        # table, StaticTargets of an earlier runner) is freed through the caching host allocator, which records and
+        # queries events -- not allowed on the capturing thread; the process then aborts, depending on when the
+        # collector happens to run (seen as a run-order dependent abort in _pack_grads).
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._capture_graphs(g, images, packed, want_opt, capturable)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture_graphs(self, g, images, packed, want_opt, capturable):
         # thread_local: RCCL's watchdog thread polls events of earlier collectives; in the default (global) mode that
         # query is an error while ANY thread captures
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
