@@ -8,9 +8,11 @@ extern "C" int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int d
 
 // implemented in conv_mfma.hip
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst);
+int mfma_conv_plan(const ConvGeom& g);
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst,
                      int accumulate, int dtype, hipStream_t st);
 int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const void* x, const void* dy);
+long mfma_wgrad2_plan(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k);
 int mfma_wgrad2_slabs(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k);
 int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* part, void* dw_oihw, int dw_dtype, int Kpad,
                        int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
@@ -310,6 +312,38 @@ int run_conv(const ConvGeom& g, const void* src, const void* wm, const float* bi
     return rc;
 }
 
+ConvGeom fwd_geom(int ldx, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride) {
+    ConvGeom g;
+    g.stats = stats_acc;
+    g.N = N; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lds = ldx;
+    g.Hd = OH; g.Wd = OW; g.Cd = Cout; g.ldd = ldy; g.Hg = OH; g.Wg = OW;
+    g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = stride;
+    int kh[9], kw[9];
+    g.ntaps = conv_taps(0, k, stride, 0, g.dh, g.dw, kh, kw);
+    g.K = g.ntaps * Cin; g.Kpad = round_up32(g.K);
+    return g;
+}
+
+// data gradient, parity class c (stride 2: four classes; stride 1: c = 0)
+ConvGeom dgrad_geom(int lddy, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int c) {
+    ConvGeom g;
+    g.stats = nullptr;
+    g.N = N; g.Hs = OH; g.Ws = OW; g.Cs = Cout; g.lds = lddy;
+    g.Hd = H; g.Wd = W; g.Cd = Cin; g.ldd = lddx;
+    int kh[9], kw[9];
+    g.ntaps = conv_taps(1, k, stride, c, g.dh, g.dw, kh, kw);
+    g.K = g.ntaps * Cout; g.Kpad = round_up32(g.K);
+    if (stride == 1) {
+        g.Hg = H; g.Wg = W; g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = 1;
+    } else {
+        int ph = c >> 1, pw = c & 1;
+        g.Hg = ph == 0 ? (H + 1) / 2 : H / 2;
+        g.Wg = pw == 0 ? (W + 1) / 2 : W / 2;
+        g.ostep = 2; g.ooff_h = ph; g.ooff_w = pw; g.sstride = 1;
+    }
+    return g;
+}
+
 bool supported(int k, int stride) { return (k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)); }
 
 }  // namespace
@@ -381,14 +415,7 @@ int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, v
     if (!supported(k, stride) || (stats_acc && bias)) return YOLO_ERR_ARG;
     int pad = k / 2;
     if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return YOLO_ERR_ARG;
-    ConvGeom g;
-    g.stats = stats_acc;
-    g.N = N; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lds = ldx;
-    g.Hd = OH; g.Wd = OW; g.Cd = Cout; g.ldd = ldy; g.Hg = OH; g.Wg = OW;
-    g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = stride;
-    int kh[9], kw[9];
-    g.ntaps = conv_taps(0, k, stride, 0, g.dh, g.dw, kh, kw);
-    g.K = g.ntaps * Cin; g.Kpad = round_up32(g.K);
+    ConvGeom g = fwd_geom(ldx, ldy, stats_acc, N, H, W, Cin, OH, OW, Cout, k, stride);
     return run_conv(g, x, wp, bias, y, 0, dtype, algo, st);
 }
 
@@ -401,21 +428,7 @@ int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int ld
     int ncls = stride == 2 ? 4 : 1;
     long off = 0;
     for (int c = 0; c < ncls; ++c) {
-        ConvGeom g;
-        g.stats = nullptr;
-        g.N = N; g.Hs = OH; g.Ws = OW; g.Cs = Cout; g.lds = lddy;
-        g.Hd = H; g.Wd = W; g.Cd = Cin; g.ldd = lddx;
-        int kh[9], kw[9];
-        g.ntaps = conv_taps(1, k, stride, c, g.dh, g.dw, kh, kw);
-        g.K = g.ntaps * Cout; g.Kpad = round_up32(g.K);
-        if (stride == 1) {
-            g.Hg = H; g.Wg = W; g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = 1;
-        } else {
-            int ph = c >> 1, pw = c & 1;
-            g.Hg = ph == 0 ? (H + 1) / 2 : H / 2;
-            g.Wg = pw == 0 ? (W + 1) / 2 : W / 2;
-            g.ostep = 2; g.ooff_h = ph; g.ooff_w = pw; g.sstride = 1;
-        }
+        ConvGeom g = dgrad_geom(lddy, lddx, N, H, W, Cin, OH, OW, Cout, k, stride, c);
         if (g.Hg > 0 && g.Wg > 0) {
             int rc = run_conv(g, dy, (const char*)wb + off * esz, nullptr, dx, accumulate, dtype, algo, st);
             if (rc) return rc;
@@ -423,6 +436,23 @@ int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int ld
         off += (long)Cin * g.Kpad;
     }
     return YOLO_OK;
+}
+
+// Which kernel a forward / data-gradient launch takes (tests assert that their shapes reach the variant they mean to cover).
+int yolo_conv2d_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int mode, int cls, int dtype) {
+    if (!supported(k, stride)) return -1;
+    const ConvGeom g = mode == 0 ? fwd_geom(Cin, Cout, nullptr, N, H, W, Cin, OH, OW, Cout, k, stride)
+                                 : dgrad_geom(Cout, Cin, N, H, W, Cin, OH, OW, Cout, k, stride, cls);
+    static const long long dummy[2] = {0, 0};               // eligibility looks at alignment only
+    if (!mfma_conv_eligible(g, dtype, dummy, dummy, dummy)) return 0;
+    return mfma_conv_plan(g);
+}
+
+long yolo_conv2d_wgrad_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype) {
+    if (!supported(k, stride)) return -1;
+    static const long long dummy[2] = {0, 0};
+    if (!mfma_wgrad_eligible(Cin, Cout, Cin, Cout, dtype, dummy, dummy)) return 0;
+    return mfma_wgrad2_plan(round_up32(k * k * Cin), N, H, W, Cin, OH, OW, Cout, k);
 }
 
 // Which weight-gradient kernel a call takes: 2 = MFMA, per-slab partial matrices + reduce (the product path),

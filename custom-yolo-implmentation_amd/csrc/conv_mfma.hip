@@ -23,6 +23,18 @@ int halo_conv_eligible(const ConvGeom& g);
 int halo_conv_launch(const ConvGeom& g, int variant, const void* src, const void* wm, const float* bias, void* dst,
                      int accumulate, int dtype, hipStream_t st);
 
+// Kernel-selection overrides (tile width, K order, halo variant, LDS-DMA), -1 / 0 = automatic.  Read ONCE per process
+// from YOLO_CONV_TUNE ("bn,tap_inner,halo,dma"); tools/conv_tune.py and the variant-forcing parity tests change them
+// through yolo_conv_tune_set.  Not part of the training path: nothing there writes them.
+struct ConvTune { int bn, tap_inner, halo, dma; };
+static ConvTune& conv_tune() {
+    static ConvTune t = [] {
+        ConvTune v{0, -1, -1, -1};
+        if (const char* e = getenv("YOLO_CONV_TUNE")) sscanf(e, "%d,%d,%d,%d", &v.bn, &v.tap_inner, &v.halo, &v.dma);
+        return v;
+    }();
+    return t;
+}
 namespace {
 
 // MODE 0: K walked tap-major (k = tap*Cs + ch), any Cs % 8 == 0; each lane tracks its own (tap, ch).
@@ -444,27 +456,30 @@ void launch_tile(const GeomDev& d, const void* src, const void* wm, const float*
 #undef CONV_LAUNCH
 }
 
-template <typename T>
-void launch_conv_t(const GeomDev& d_in, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
-                   hipStream_t st) {
-    // Tile width (tools/conv_tune.py on MI355X): the widest channel tile that still yields one workgroup per CU --
-    // small maps with many channels (20x20, K in the thousands) otherwise run ~100 workgroups through a 144-step
-    // K loop on a 256-CU chip; narrower tiles than that only add LDS reads per MFMA.  One-tap convs whose source
-    // stays in the 256 MB Infinity Cache prefer 64-wide tiles (re-reading the source per channel tile is cheap there).
+// Tile width (tools/conv_tune.py on MI355X): the widest channel tile that still yields one workgroup per CU --
+// small maps with many channels (20x20, K in the thousands) otherwise run ~100 workgroups through a 144-step
+// K loop on a 256-CU chip; narrower tiles than that only add LDS reads per MFMA.  One-tap convs whose source
+// stays in the 256 MB Infinity Cache prefer 64-wide tiles (re-reading the source per channel tile is cheap there).
+int conv_tile_bn(const GeomDev& d_in) {
     const long tm = ((long)d_in.N * d_in.Hg * d_in.Wg + BM - 1) / BM;
     auto blocks = [&](int bn) { return tm * ((d_in.Cd + bn - 1) / bn); };
     int bn = d_in.Cd > 64 ? 128 : (d_in.Cd > 32 ? 64 : 32);
     const long src_bytes = (long)d_in.N * d_in.Hs * d_in.Ws * d_in.lds * 2;
     if (bn == 128 && d_in.ntaps == 1 && src_bytes <= (128L << 20)) bn = 64;
     while (bn > 32 && blocks(bn) < 256) bn >>= 1;
+    const ConvTune& tu = conv_tune();                        // overrides: tuning runs and variant-forcing tests only
+    if (tu.bn == 32 || tu.bn == 64 || tu.bn == 128) bn = tu.bn;
+    return bn;
+}
+
+template <typename T>
+void launch_conv_t(const GeomDev& d_in, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+                   hipStream_t st) {
+    const int bn = conv_tile_bn(d_in);
     GeomDev d = d_in;
-    if (const char* e = getenv("YOLO_CONV_TUNE")) {          // "bn,tap_inner,halo,dma": tuning runs only
-        int v[4] = {0, -1, -1, -1};
-        sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-        if (v[0] == 32 || v[0] == 64 || v[0] == 128) bn = v[0];
-        if (v[1] >= 0) d.tap_inner = v[1];
-        if (v[3] >= 0) d.dma = v[3];
-    }
+    const ConvTune& tu = conv_tune();
+    if (tu.tap_inner >= 0) d.tap_inner = tu.tap_inner;
+    if (tu.dma >= 0) d.dma = tu.dma;
     if (bn == 128) launch_tile<T, 2, 2, 4, 4>(d, src, wm, bias, dst, accumulate, st);        // 128 x 128
     else if (bn == 64) launch_tile<T, 2, 2, 4, 2>(d, src, wm, bias, dst, accumulate, st);    // 128 x 64
     else launch_tile<T, 4, 1, 2, 2>(d, src, wm, bias, dst, accumulate, st);                  // 128 x 32
@@ -473,6 +488,12 @@ void launch_conv_t(const GeomDev& d_in, const void* src, const void* wm, const f
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma) {
+    ConvTune& t = conv_tune();
+    t.bn = bn; t.tap_inner = tap_inner; t.halo = halo; t.dma = dma;
+    return YOLO_OK;
+}
 
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst) {
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
@@ -487,15 +508,10 @@ int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void
 }
 
 // 3x3 stride-1 layers take the halo kernel (conv_halo.hip) when the map is large enough for its 8x16 / 16x16 pixel
-// tiles to fill the chip; variant choice from tools/conv_tune.py.  YOLO_CONV_TUNE's third field overrides it
-// (0 = gather kernel, 1..4 = halo variant) for tuning runs.
+// tiles to fill the chip; variant choice from tools/conv_tune.py.  yolo_conv_tune_set's third field overrides it
+// (0 = gather kernel, 1..4 = halo variant) for tuning runs and the variant-forcing parity tests.
 static int halo_variant(const ConvGeom& g) {
-    int v = -1;
-    if (const char* e = getenv("YOLO_CONV_TUNE")) {
-        int a = 0, b = 0, c = -1;
-        sscanf(e, "%d,%d,%d", &a, &b, &c);
-        v = c;
-    }
+    const int v = conv_tune().halo;
     if (!halo_conv_eligible(g)) return 0;
     if (v >= 0) return v > 4 ? 0 : v;
     // measured in the training step (preset s, 32 images): the halo kernel wins on maps of 80x80 and more
@@ -504,6 +520,11 @@ static int halo_variant(const ConvGeom& g) {
     if ((long)g.Hg * g.Wg >= 80 * 80) return g.Cd >= 128 ? 2 : 3;
     if (g.Hg >= 40 && g.Wg >= 40 && g.Cd == 128) return 1;
     return 0;
+}
+
+int mfma_conv_plan(const ConvGeom& g) {
+    if (const int hv = halo_variant(g)) return 2000 + hv;
+    return 1000 + conv_tile_bn(to_dev(g));
 }
 
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst, int accumulate,

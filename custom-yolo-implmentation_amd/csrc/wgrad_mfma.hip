@@ -248,6 +248,19 @@ void launch_reduce(const float* part, int nslab, int Cout, int Cin, int NT, int 
 
 struct WgPlan { int to, ti, cot, cit, nslab; long per_slab; };
 
+// Plan overrides (tile, workgroup count), 0 = automatic.  Read ONCE per process from YOLO_WG_TUNE ("to,ti,blocks,min_per")
+// and YOLO_WG_BLOCKS; tools/wg_tune.py and the plan-forcing parity tests change them through yolo_wgrad_tune_set.
+struct WgTune { int to, ti, blocks, min_per; long all_blocks; };
+WgTune& wg_tune() {
+    static WgTune t = [] {
+        WgTune v{0, 0, 0, 0, 0};
+        if (const char* e = getenv("YOLO_WG_TUNE")) sscanf(e, "%d,%d,%d,%d", &v.to, &v.ti, &v.blocks, &v.min_per);
+        if (const char* e2 = getenv("YOLO_WG_BLOCKS")) v.all_blocks = atol(e2);
+        return v;
+    }();
+    return t;
+}
+
 // tile and slab choice (shared by the workspace query and the launch)
 WgPlan make_plan(const WgArgs& a, int k) {
     WgPlan p;
@@ -269,8 +282,9 @@ WgPlan make_plan(const WgArgs& a, int k) {
     const int cot0 = (a.Cout + 32 * p.to - 1) / (32 * p.to), cit0 = (a.Cin + 32 * p.ti - 1) / (32 * p.ti);
     const long data_bytes = ((long)a.N * a.H * a.W * a.Cin + (long)a.N * a.OH * a.OW * a.Cout) * 2;
     long want_blocks;
-    if (const char* e2 = getenv("YOLO_WG_BLOCKS")) {         // tuning runs only: one count for every layer
-        want_blocks = atol(e2);
+    const WgTune& tu = wg_tune();                             // overrides: tuning runs and plan-forcing tests only
+    if (tu.all_blocks > 0) {                                  // one count for every layer
+        want_blocks = tu.all_blocks;
     } else if (k == 1) {
         if (p.to * p.ti == 1) want_blocks = 2048;                                  // 32 x 32 tiles: 4 KB partials
         else want_blocks = (cot0 * cit0 == 1 && data_bytes < (150L << 20)) ? 256 : 512;
@@ -278,14 +292,10 @@ WgPlan make_plan(const WgArgs& a, int k) {
         want_blocks = p.ti == 1 ? 512 : 256;                                       // 64 x 32 x 9 vs 64 x 64 x 9 tiles
     }
     long min_per = 2;
-    if (const char* e = getenv("YOLO_WG_TUNE")) {            // "to,ti,blocks,min_per": tuning runs only
-        int v[4] = {0, 0, 0, 0};
-        sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-        if (v[0] > 0 && (k == 1 || v[0] <= 2)) p.to = v[0];
-        if (v[1] > 0 && (k == 1 || v[1] <= 2)) p.ti = v[1];
-        if (v[2] > 0) want_blocks = v[2];
-        if (v[3] > 0) min_per = v[3];
-    }
+    if (tu.to > 0 && (k == 1 || tu.to <= 2)) p.to = tu.to;
+    if (tu.ti > 0 && (k == 1 || tu.ti <= 2)) p.ti = tu.ti;
+    if (tu.blocks > 0) want_blocks = tu.blocks;
+    if (tu.min_per > 0) min_per = tu.min_per;
     p.cot = (a.Cout + 32 * p.to - 1) / (32 * p.to);
     p.cit = (a.Cin + 32 * p.ti - 1) / (32 * p.ti);
     // ~2 workgroups per CU for 3x3 (144 accumulator registers), ~4 for 1x1; every workgroup ends by storing its
@@ -341,11 +351,24 @@ WgArgs make_args(int ldx, int ldy, int Kpad, int N, int H, int W, int Cin, int O
 
 }  // namespace
 
+extern "C" int yolo_wgrad_tune_set(int to, int ti, int blocks, int min_per) {
+    WgTune& t = wg_tune();
+    t.to = to; t.ti = ti; t.blocks = blocks; t.min_per = min_per;
+    return YOLO_OK;
+}
+
 // number of [Cout][Kpad] fp32 partial matrices the launch below writes (same eligibility as the first design)
 int mfma_wgrad2_slabs(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k) {
     WgArgs a = make_args(0, 0, Kpad, N, H, W, Cin, OH, OW, Cout);
     if (a.npatch == 0) return 1;
     return make_plan(a, k).nslab;
+}
+
+long mfma_wgrad2_plan(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k) {
+    WgArgs a = make_args(0, 0, Kpad, N, H, W, Cin, OH, OW, Cout);
+    if (a.npatch == 0) return 0;
+    const WgPlan p = make_plan(a, k);
+    return p.to * 1000000L + p.ti * 100000L + p.nslab;
 }
 
 // part[nslab][Cout][Kpad] (fp32 scratch, need not be zeroed) <- per-slab partial gradients, then

@@ -67,6 +67,16 @@ int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, v
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
 long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo);
 int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws, void* dw_oihw, int dw_dtype, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
+/* kernel-selection overrides for tuning runs (tools/conv_tune.py, tools/wg_tune.py) and the variant-forcing parity tests
+   (tests/test_gpu_conv_variants.py); process-wide, 0 / -1 = automatic; the training path never calls them.
+   conv: bn in {0, 32, 64, 128}, tap_inner / dma in {-1, 0, 1}, halo in {-1, 0 (gather kernel), 1..4}.  No reference counterpart (model_blocks.py:27). */
+int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma);
+int yolo_wgrad_tune_set(int to, int ti, int blocks, int min_per);
+/* which kernel a forward (mode 0) / data-gradient (mode 1, parity class cls for stride 2) launch of this shape takes:
+   kind * 1000 + width, kind 1 = gather MFMA kernel (width = channel tile 32/64/128), 2 = halo MFMA kernel (width = variant 1..4), 0 = VALU kernels */
+int yolo_conv2d_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int mode, int cls, int dtype);
+/* weight-gradient plan of a shape: to * 1000000 + ti * 100000 + nslab (MFMA path), 0 = other paths */
+long yolo_conv2d_wgrad_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype);
 /* stem (3 -> C, 3x3 stride 2: backbone.py:38): NCHW image unfolded to K = 27(+5) columns, then the 1x1 MFMA path */
 int yolo_stem_im2col(const void* img, int img_dtype, void* col, int col_dtype, int N, int H, int W, int OH, int OW, hipStream_t st);
 int yolo_stem_pack_weights(const void* w, int w_dtype, int Cout, void* out, int out_dtype, hipStream_t st);

@@ -1,0 +1,288 @@
+"""-m gpu: element-wise parity of the conv kernels THAT THE BENCH RUNS against a plain fp32 torch reference on the CPU.
+
+tests/test_gpu_kernels.py covers every leaf on small maps, where the launcher always picks the narrowest tile.
+Here the variants that carry the measured step are selected on purpose:
+  * forced (yolo_conv_tune_set / yolo_wgrad_tune_set) on maps whose pixel count is not a multiple of any tile size, so
+    the last tile is partial: every channel-tile width of the gather kernel in its register-staged and LDS-DMA forms,
+    accumulate on and off, every halo-kernel variant, every weight-gradient tile;
+  * by the launcher's own choice on the shapes, row strides and batch size of BASELINE config 2 (preset s, 640x640,
+    32 images): the calls of one real training step are recorded and each distinct one is replayed on seeded data --
+    forward and data gradient checked on the images where tiles begin, straddle and end, the weight gradient on all 32.
+Inputs are rounded to bf16 first, the reference accumulates them in fp32 (F.conv2d / conv2d_input / conv2d_weight),
+the kernels accumulate in fp32 and round once: per element |err| <= 2^-8 |ref| + 1e-3 max|ref| (one bf16 ulp of the
+element plus accumulation-order noise); fp32 weight gradients 3e-4 of the tensor's max."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def ops():
+    from src.hipops import ops as o
+    return o
+
+
+def lib():
+    from src.hipops import lib as l
+    return l
+
+
+@pytest.fixture(autouse=True)
+def _reset_tuning():
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    yield
+    lib().call("yolo_conv_tune_set", 0, -1, -1, -1)
+    lib().call("yolo_wgrad_tune_set", 0, 0, 0, 0)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def on_dev(t, ld=None, fill=3.0):
+    """NCHW-shaped CPU tensor -> NHWC device tensor; with ld > C a channel slice in the middle of a wider buffer whose
+    other channels hold `fill` (a kernel that strays outside its slice reads or clobbers them)."""
+    o = ops()
+    n, c, h, w = t.shape
+    ld = c if ld is None else ld
+    buf = o.new_nhwc(n, ld, h, w, t.dtype, DEV)
+    buf.fill_(fill)
+    off = ((ld - c) // 2) // 8 * 8
+    view = buf[:, off:off + c]
+    view.copy_(t.to(DEV))
+    return view, buf, off
+
+
+def assert_elem(got, want, what, rel=2.0 ** -8, floor=1e-3):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    lim = rel * want.abs() + floor * float(want.abs().max())
+    bad = (got - want).abs() > lim
+    if bool(bad.any()):
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements off; first at {idx}: got "
+                             f"{float(got[tuple(idx)]):.5f} want {float(want[tuple(idx)]):.5f} (max |ref| {float(want.abs().max()):.3f})")
+
+
+def assert_slice_untouched(buf, off, c, fill, what):
+    """channels of the wider buffer outside [off, off+c) still hold the fill value"""
+    outside = torch.cat([buf[:, :off], buf[:, off + c:]], 1)
+    assert bool((outside.float() == fill).all()), f"{what}: wrote outside its channel slice"
+
+
+def run_fwd_dgrad_case(n, cin, cout, h, w, k, s, images, ldx=None, ldy=None, stats=True, acc=(False, True), seed=0,
+                       want_plan=None):
+    """forward (+ BatchNorm statistics epilogue) and data gradient (+ accumulate form) of one shape against the CPU
+    reference evaluated on `images` (conv is per image)."""
+    o = ops()
+    q = lib().query
+    oh, ow = o.conv_out_hw(h, w, k, s)
+    if want_plan is not None:
+        got = q("yolo_conv2d_plan", n, h, w, cin, oh, ow, cout, k, s, 0, 0, lib().BF16)
+        assert got == want_plan, f"test does not reach the variant it is written for: plan {got}, wanted {want_plan}"
+    x, wt = rnd((n, cin, h, w), seed + 1), rnd((cout, cin, k, k), seed + 2, (cin * k * k) ** -0.5).float()
+    images = sorted(set(i for i in images if i < n))
+    wp, wb = o.pack_weights(wt.to(DEV), k, s, 0, BF), o.pack_weights(wt.to(DEV), k, s, 1, BF)
+    wref = wt.to(BF).float()
+    # ---- forward
+    xd, _, _ = on_dev(x, ldx)
+    ybuf = o.new_nhwc(n, ldy or cout, oh, ow, BF, DEV).fill_(5.0)
+    yoff = (((ldy or cout) - cout) // 2) // 8 * 8
+    yv = ybuf[:, yoff:yoff + cout]
+    acc_s = o.bn_acc_new(cout, DEV) if stats else None
+    y = o.conv_fwd(xd, wp, None, cout, k, s, acc_s, out=yv)
+    y_ref = F.conv2d(x[images].float(), wref, None, s, k // 2)
+    assert_elem(y[images], y_ref, f"conv_fwd {(n, cin, h, w, cout, k, s)}")
+    assert_slice_untouched(ybuf, yoff, cout, 5.0, "conv_fwd")
+    if stats:
+        yf = y.float()
+        sums = acc_s.view(o.BN_REPL, 2, cout).sum(0).cpu()
+        want = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]).cpu()
+        mass = torch.stack([yf.abs().sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]).cpu()
+        assert bool(((sums - want).abs() <= 2e-5 * mass + 1e-3).all()), f"BN statistics epilogue: {(sums - want).abs().max()}"
+    # ---- data gradient
+    if cin % 8:
+        return
+    dy = rnd((n, cout, oh, ow), seed + 3)
+    dyd, _, _ = on_dev(dy, ldy)
+    dx_ref = torch.nn.grad.conv2d_input((len(images), cin, h, w), wref, dy[images].float(), s, k // 2)
+    for accumulate in acc:
+        base = rnd((n, cin, h, w), seed + 4)
+        dxv, dxbuf, dxoff = on_dev(base, ldx, fill=9.0)
+        if accumulate:
+            o.conv_dgrad(dyd, wb, cin, h, w, k, s, acc_into=dxv)
+            want = (dx_ref + base[images].float())
+            got = dxv
+        else:
+            got = o.conv_dgrad(dyd, wb, cin, h, w, k, s)
+            want = dx_ref
+        assert_elem(got[images], want, f"conv_dgrad acc={accumulate} {(n, cin, h, w, cout, k, s)}")
+        if accumulate:
+            assert_slice_untouched(dxbuf, dxoff, cin, 9.0, "conv_dgrad")
+
+
+def run_wgrad_case(n, cin, cout, h, w, k, s, ldx=None, ldy=None, seed=0):
+    o = ops()
+    oh, ow = o.conv_out_hw(h, w, k, s)
+    x, dy = rnd((n, cin, h, w), seed + 5), rnd((n, cout, oh, ow), seed + 6)
+    xd, _, _ = on_dev(x, ldx)
+    dyd, _, _ = on_dev(dy, ldy)
+    dw = o.conv_wgrad(xd, dyd, k, s, torch.float32)
+    dw_ref = torch.nn.grad.conv2d_weight(x.float(), (cout, cin, k, k), dy.float(), s, k // 2)
+    err = float((dw.cpu() - dw_ref).abs().max())
+    assert err <= 3e-4 * float(dw_ref.abs().max()), f"conv_wgrad {(n, cin, h, w, cout, k, s)}: {err:.3e} vs max {float(dw_ref.abs().max()):.3e}"
+
+
+# ------------------------------------------------------------------------------------------ forced variants
+# maps of 37 x 41 (1517 pixels per image: no multiple of 128, 16 or 8) so the last pixel tile of every kernel is partial;
+# channel counts that are / are not multiples of the channel tile
+@pytest.mark.parametrize("bn", [32, 64, 128])
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("cin,cout,k,s", [(64, 128, 3, 1), (96, 200, 1, 1), (64, 64, 3, 2), (32, 136, 3, 1)])
+def test_gather_kernel_every_tile_width_and_staging_mode(bn, dma, cin, cout, k, s):
+    lib().call("yolo_conv_tune_set", bn, -1, 0, dma)
+    run_fwd_dgrad_case(3, cin, cout, 37, 41, k, s, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=1000 + bn,
+                       seed=bn + dma)
+
+
+@pytest.mark.parametrize("bn", [64, 128])
+def test_gather_kernel_tap_inner_order(bn):
+    lib().call("yolo_conv_tune_set", bn, 1, 0, 1)
+    run_fwd_dgrad_case(2, 64, 128, 23, 29, 3, 1, images=[0, 1], want_plan=1000 + bn, seed=7)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64), (96, 192)])
+def test_halo_kernel_every_variant(variant, cin, cout):
+    lib().call("yolo_conv_tune_set", 0, -1, variant, -1)
+    run_fwd_dgrad_case(3, cin, cout, 37, 41, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=2000 + variant,
+                       seed=variant)
+
+
+@pytest.mark.parametrize("to,ti", [(1, 1), (1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("k,s", [(3, 1), (3, 2)])
+def test_wgrad_3x3_every_tile(to, ti, k, s):
+    lib().call("yolo_wgrad_tune_set", to, ti, 0, 0)
+    run_wgrad_case(3, 72, 88, 37, 41, k, s, ldx=104, ldy=96, seed=to * 4 + ti)
+
+
+@pytest.mark.parametrize("to", [1, 2, 3, 4])
+@pytest.mark.parametrize("ti", [1, 2, 3, 4])
+def test_wgrad_1x1_every_tile(to, ti):
+    lib().call("yolo_wgrad_tune_set", to, ti, 0, 0)
+    run_wgrad_case(3, 136, 120, 37, 41, 1, 1, ldx=160, ldy=128, seed=to * 4 + ti)
+
+
+# ------------------------------------------------------------------------------------------ the bench's own calls
+def _record_step_calls(cfg, n, res):
+    """One real bf16 training step of the model; -> distinct dense-conv calls as the launcher saw them."""
+    from oracle import blocks as ob
+    from oracle.params import det_fill_
+    from src.model.losses import YoloDFLQFLoss
+    from src.model.model_builder import Model
+    o = ops()
+    calls = {"fwd": set(), "dgrad": set(), "wgrad": set()}
+    real = (o.conv_fwd, o.conv_dgrad, o.conv_wgrad)
+
+    def fwd(x, wp, bias, cout, k, stride, stats_acc=None, out=None):
+        y = real[0](x, wp, bias, cout, k, stride, stats_acc, out)
+        nn, cin, h, w, ldx = o.geom(x)
+        calls["fwd"].add((nn, cin, cout, h, w, k, stride, ldx, o.geom(y)[4], stats_acc is not None))
+        return y
+
+    def dgrad(dy, wb, cin, h, w, k, stride, acc_into=None):
+        dx = real[1](dy, wb, cin, h, w, k, stride, acc_into)
+        nn, cout, _, _, lddy = o.geom(dy)
+        calls["dgrad"].add((nn, cin, cout, h, w, k, stride, o.geom(dx)[4], lddy, acc_into is not None))
+        return dx
+
+    def wgrad(x, dy, k, stride, w_dtype, out=None):
+        nn, cin, h, w, ldx = o.geom(x)
+        calls["wgrad"].add((nn, cin, dy.shape[1], h, w, k, stride, ldx, o.geom(dy)[4]))
+        return real[2](x, dy, k, stride, w_dtype, out)
+
+    o.conv_fwd, o.conv_dgrad, o.conv_wgrad = fwd, dgrad, wgrad
+    try:
+        model = Model(**ob.PRESETS[cfg], num_classes=80)
+        det_fill_(model.state_dict(), 1)
+        model = model.cuda().train()
+        g = torch.Generator().manual_seed(3)
+        img = torch.randn(n, 3, res, res, generator=g).cuda()
+        gts = [torch.tensor([[res * 0.5, res * 0.4, res * 0.2, res * 0.1, 4.]]).cuda() for _ in range(n)]
+        with torch.autocast("cuda", dtype=BF):
+            preds, a, st = model(img)
+            loss, _ = YoloDFLQFLoss(num_classes=80)(preds, gts, a, st)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        o.conv_fwd, o.conv_dgrad, o.conv_wgrad = real
+    return calls
+
+
+@pytest.fixture(scope="module")
+def config2_calls():
+    return _record_step_calls("s", 32, 640)
+
+
+def test_config2_forward_and_dgrad_calls_elementwise(config2_calls):
+    """Every distinct forward / data-gradient call of preset s @640, 32 images, replayed with the recorded strides and
+    the launcher's own variant choice; reference on the images where pixel tiles begin, straddle and end."""
+    q = lib().query
+    plans, failures = {}, []
+    shapes = {}
+    for (n, cin, cout, h, w, k, s, ldx, ldy, st) in sorted(config2_calls["fwd"]):
+        shapes.setdefault((n, cin, cout, h, w, k, s), [ldx, ldy, st, False])
+    for (n, cin, cout, h, w, k, s, lddx, lddy, acc) in sorted(config2_calls["dgrad"]):
+        e = shapes.setdefault((n, cin, cout, h, w, k, s), [lddx, lddy, False, acc])
+        e[3] = e[3] or acc
+    assert len(shapes) >= 20
+    for (n, cin, cout, h, w, k, s), (ldx, ldy, st, acc) in shapes.items():
+        if cin < 8:
+            continue                                     # the 3-channel stem has its own kernels and tests
+        oh, ow = ops().conv_out_hw(h, w, k, s)
+        p = q("yolo_conv2d_plan", n, h, w, cin, oh, ow, cout, k, s, 0, 0, lib().BF16)
+        plans[p] = plans.get(p, 0) + 1
+        try:
+            run_fwd_dgrad_case(n, cin, cout, h, w, k, s, images=[0, 1, 13, n - 2, n - 1], ldx=ldx, ldy=ldy, stats=st,
+                               acc=(False, True) if acc else (False,), seed=cin + cout)
+        except AssertionError as e:
+            failures.append(str(e))
+    print(f"\n[config-2 conv calls] {len(shapes)} distinct shapes, forward plans (kind*1000+width -> count): {plans}")
+    assert not failures, "\n".join(failures)
+    # the step must have exercised the wide tiles and the halo kernel (what the bench's time is made of)
+    assert any(p in plans for p in (1064, 1128)) and any(p // 1000 == 2 for p in plans), plans
+
+
+def test_config2_weight_gradient_calls_elementwise(config2_calls):
+    """Every distinct weight-gradient call of preset s @640 at the full 32 images (the slab plan depends on the batch)."""
+    q = lib().query
+    failures, plans = [], set()
+    calls = sorted(config2_calls["wgrad"])
+    assert len(calls) >= 20
+    for (n, cin, cout, h, w, k, s, ldx, ldy) in calls:
+        if cin % 8:
+            continue
+        oh, ow = ops().conv_out_hw(h, w, k, s)
+        plans.add(q("yolo_conv2d_wgrad_plan", n, h, w, cin, oh, ow, cout, k, s, lib().BF16))
+        try:
+            run_wgrad_case(n, cin, cout, h, w, k, s, ldx=ldx, ldy=ldy, seed=cin * 3 + cout)
+        except AssertionError as e:
+            failures.append(str(e))
+    print(f"\n[config-2 wgrad calls] {len(calls)} distinct calls, {len(plans)} distinct plans")
+    assert not failures, "\n".join(failures)
+
+
+def test_stride2_dgrad_real_shape_all_parity_classes():
+    """128 -> 128 3x3 stride 2 on a 160 x 160 map, 32 images (the biggest conv of preset s): four parity-class launches."""
+    q = lib().query
+    got = [q("yolo_conv2d_plan", 32, 160, 160, 128, 80, 80, 128, 3, 2, 1, c, lib().BF16) for c in range(4)]
+    assert all(g // 1000 == 1 for g in got), got
+    run_fwd_dgrad_case(32, 128, 128, 160, 160, 3, 2, images=[0, 17, 31], stats=True, acc=(False, True), seed=77)
+    # odd map: the parity classes have different sizes
+    run_fwd_dgrad_case(2, 64, 64, 45, 39, 3, 2, images=[0, 1], stats=False, seed=78)

@@ -136,8 +136,8 @@ def test_checkpoint_round_trip_across_wrappers(pg, mode, tmp_path):
     assert len(st) > 0 and all("exp_avg" in v for v in st.values())
 
 
-@pytest.mark.parametrize("group", [1, 3, 8])
-def test_runner_gradients_equal_plain_autograd(group, monkeypatch):
+@pytest.mark.parametrize("group,precision", [(1, "float32"), (3, "float32"), (8, "float32"), (3, "bfloat16"), (8, "bfloat16")])
+def test_runner_gradients_equal_plain_autograd(group, precision, monkeypatch):
     """TrainStepRunner runs the conv weight gradients on a side stream that is joined lazily, several layers per
     sync point; the gradients it leaves in .grad -- eagerly and after graph replays -- must be those of a plain
     `loss.backward()`.  (Regression: a gradient tensor that was also referenced by the pending-work queue was CLONED
@@ -159,10 +159,17 @@ def test_runner_gradients_equal_plain_autograd(group, monkeypatch):
     def grads():
         return [p.grad.detach().float().clone() for p in model.parameters() if p.grad is not None]
 
+    amp = torch.bfloat16 if precision == "bfloat16" else None
+    # bf16: the same MFMA kernels in the same order on both sides; what differs is the arrival order of the float
+    # atomics behind the batch statistics, i.e. last-bit noise of fp32 sums that a bf16 rounding can turn into one ulp
+    tol = 1e-3 if amp is None else 3e-2
+
     def plain(image):                                       # plain autograd: per-layer fork/join inside each backward
         model.zero_grad(set_to_none=True)
-        preds, anchors, strides = model(image)
-        crit(preds, packed, anchors, strides)[0].backward()
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            preds, anchors, strides = model(image)
+            loss = crit(preds, packed, anchors, strides)[0]
+        loss.backward()
         torch.cuda.synchronize()
         return grads()
 
@@ -170,20 +177,20 @@ def test_runner_gradients_equal_plain_autograd(group, monkeypatch):
         gmax = max(float(a.abs().max()) for a in want)
         for a, b in zip(want, got):
             scale = a.abs().max().clamp_min(1e-3 * gmax)
-            assert (a - b).abs().max() / scale < 1e-3, what
+            assert (a - b).abs().max() / scale < tol, (what, float((a - b).abs().max() / scale))
 
     want = plain(img)
     plain(torch.randn(2, 3, 160, 160, generator=g).cuda())  # freed blocks now hold ANOTHER batch's gradients
     opt = torch.optim.AdamW(model.parameters(), lr=0.0, weight_decay=0.0, capturable=True, fused=True)
     model.zero_grad(set_to_none=True)
-    r = TrainStepRunner(model, crit, opt, "float32", use_graph=False)
+    r = TrainStepRunner(model, crit, opt, precision, use_graph=False)
     r._fwd_bwd(img, packed)
     torch.cuda.synchronize()
     check(want, grads(), "eager runner step")
     r._fwd_bwd(img, packed)                                 # .grad present: autograd accumulates at once, so the runner
     torch.cuda.synchronize()                                # must not defer the weight gradients of this call
     check([2 * a for a in want], grads(), "accumulating second backward")
-    r = TrainStepRunner(model, crit, opt, "float32", use_graph=True)
+    r = TrainStepRunner(model, crit, opt, precision, use_graph=True)
     r.capture(img, packed, warmup=1)
     with torch.no_grad():                                   # new weights: last replay's gradients are now WRONG ones,
         for p in model.parameters():                        # and the static gradient buffers are poisoned

@@ -3,7 +3,10 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "custom-yolo-implmentation_amd"))
 import torch
-from src.hipops import ops
+from src.hipops import lib, ops
+
+def tune(bn=0, tap_inner=-1, halo=-1, dma=-1):
+    lib.call("yolo_conv_tune_set", bn, tap_inner, halo, dma)
 
 def timeit(fn, secs=0.15):
     for _ in range(3): fn()
@@ -33,19 +36,19 @@ for (n, cin, h, w, cout, k, s) in shapes:
     wp = ops.pack_weights(wt, k, s, 0, torch.bfloat16)
     wb = ops.pack_weights(wt, k, s, 1, torch.bfloat16)
     for name, fn in (("fwd", lambda: ops.conv_fwd(x, wp, None, cout, k, s)), ("dgrad", lambda: ops.conv_dgrad(dy, wb, cin, h, w, k, s))):
-        os.environ.pop("YOLO_CONV_TUNE", None)
+        tune()
         base = timeit(fn)
         res = []
         for bn in (128, 64, 32):
             for ti in ((0, 1) if k == 3 else (0,)):
-                os.environ["YOLO_CONV_TUNE"] = f"{bn},{ti},0"
+                tune(bn, ti, 0)
                 res.append((timeit(fn, 0.08), bn, ti))
         for bn in (128, 64, 32):
-            os.environ["YOLO_CONV_TUNE"] = f"{bn},0,0,1"
+            tune(bn, 0, 0, 1)
             res.append((timeit(fn, 0.08), f"{bn}dma", 0))
         if k == 3 and s == 1:
             for hv in (1, 2, 3, 4):
-                os.environ["YOLO_CONV_TUNE"] = f"0,0,{hv}"
+                tune(0, 0, hv)
                 res.append((timeit(fn, 0.08), "halo", hv))
         res.sort()
         mb = (x.numel() + dy.numel()) * 2 / 1e6

@@ -3,7 +3,7 @@ import os, sys, time, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "custom-yolo-implmentation_amd"))
 import torch
-from src.hipops import ops
+from src.hipops import lib, ops
 
 def timeit(fn, secs=0.25):
     for _ in range(3): fn()
@@ -29,14 +29,14 @@ for (n, cin, h, w, cout, k, s) in shapes:
     x = torch.randn(n, cin, h, w, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     oh, ow = ops.conv_out_hw(h, w, k, s)
     dy = torch.randn(n, cout, oh, ow, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    os.environ.pop("YOLO_WG_TUNE", None)
+    lib.call("yolo_wgrad_tune_set", 0, 0, 0, 0)
     base = timeit(lambda: ops.conv_wgrad(x, dy, k, s, torch.float32))
     best = []
     tiles = [(a, b) for a in (1, 2, 3, 4) for b in (1, 2, 3, 4)] if k == 1 else [(1, 1), (1, 2), (2, 1), (2, 2)]
     tiles = [(a, b) for a, b in tiles if 32 * (a - 1) < cout and 32 * (b - 1) < cin]
     for (to, ti) in tiles:
         for blocks in (64, 128, 256, 512, 1024, 2048):
-            os.environ["YOLO_WG_TUNE"] = f"{to},{ti},{blocks},2"
+            lib.call("yolo_wgrad_tune_set", to, ti, blocks, 2)
             try:
                 us = timeit(lambda: ops.conv_wgrad(x, dy, k, s, torch.float32), 0.1)
             except Exception as e:
