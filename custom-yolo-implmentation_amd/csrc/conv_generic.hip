@@ -8,7 +8,11 @@ extern "C" int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int d
 
 // implemented in conv_mfma.hip
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst);
-int mfma_conv_plan(const ConvGeom& g);
+int mfma_conv_plan(const ConvGeom& g, int dtype);
+int ring_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst);
+int ring_conv_plan(const ConvGeom* gs, int n);
+int ring_conv_launch(const ConvGeom* gs, int n, const long* wm_off, long wm_elems, const void* src, const void* wm,
+                     const float* bias, void* dst, int accumulate, int dtype, hipStream_t st);
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst,
                      int accumulate, int dtype, hipStream_t st);
 int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const void* x, const void* dy);
@@ -426,14 +430,23 @@ int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int ld
     if (!supported(k, stride)) return YOLO_ERR_ARG;
     size_t esz = dtype == YOLO_F32 ? 4 : 2;
     int ncls = stride == 2 ? 4 : 1;
-    long off = 0;
+    ConvGeom gs[4];
+    long offs[4], off = 0;
+    bool ring = algo != 1 && stride == 2;
     for (int c = 0; c < ncls; ++c) {
-        ConvGeom g = dgrad_geom(lddy, lddx, N, H, W, Cin, OH, OW, Cout, k, stride, c);
+        gs[c] = dgrad_geom(lddy, lddx, N, H, W, Cin, OH, OW, Cout, k, stride, c);
+        offs[c] = off;
+        ring = ring && ring_conv_eligible(gs[c], dtype, dy, wb, dx);
+        off += (long)Cin * gs[c].Kpad;
+    }
+    if (ring)                                                 // one launch for the four parity classes
+        return ring_conv_launch(gs, 4, offs, off, dy, wb, nullptr, dx, accumulate, dtype, st);
+    for (int c = 0; c < ncls; ++c) {
+        const ConvGeom& g = gs[c];
         if (g.Hg > 0 && g.Wg > 0) {
-            int rc = run_conv(g, dy, (const char*)wb + off * esz, nullptr, dx, accumulate, dtype, algo, st);
+            int rc = run_conv(g, dy, (const char*)wb + offs[c] * esz, nullptr, dx, accumulate, dtype, algo, st);
             if (rc) return rc;
         }
-        off += (long)Cin * g.Kpad;
     }
     return YOLO_OK;
 }
@@ -445,7 +458,16 @@ int yolo_conv2d_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int
                                  : dgrad_geom(Cout, Cin, N, H, W, Cin, OH, OW, Cout, k, stride, cls);
     static const long long dummy[2] = {0, 0};               // eligibility looks at alignment only
     if (!mfma_conv_eligible(g, dtype, dummy, dummy, dummy)) return 0;
-    return mfma_conv_plan(g);
+    if (mode == 1 && stride == 2) {                           // the four parity classes go out as one ring launch when all qualify
+        ConvGeom gs[4];
+        bool all = true;
+        for (int c = 0; c < 4; ++c) {
+            gs[c] = dgrad_geom(Cout, Cin, N, H, W, Cin, OH, OW, Cout, k, stride, c);
+            all = all && ring_conv_eligible(gs[c], dtype, dummy, dummy, dummy);
+        }
+        if (all) return ring_conv_plan(gs, 4);
+    }
+    return mfma_conv_plan(g, dtype);
 }
 
 long yolo_conv2d_wgrad_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype) {

@@ -55,3 +55,9 @@ static inline int conv_taps(int mode, int k, int stride, int cls, int* dh, int* 
         }
     return n;
 }
+
+// Kernel-selection overrides (tile widths, K order, halo variant, LDS-DMA, ring kernel on/off, ring depth); 0 / -1 =
+// automatic.  Read ONCE per process from YOLO_CONV_TUNE ("bn,tap_inner,halo,dma,ring,bm,nst,bk"); tools/conv_tune.py and the
+// variant-forcing parity tests change them through yolo_conv_tune_set.  Nothing on the training path writes them.
+struct ConvTune { int bn, tap_inner, halo, dma, ring, bm, nst, bk; };
+ConvTune& conv_tune();

@@ -23,18 +23,21 @@ int halo_conv_eligible(const ConvGeom& g);
 int halo_conv_launch(const ConvGeom& g, int variant, const void* src, const void* wm, const float* bias, void* dst,
                      int accumulate, int dtype, hipStream_t st);
 
-// Kernel-selection overrides (tile width, K order, halo variant, LDS-DMA), -1 / 0 = automatic.  Read ONCE per process
-// from YOLO_CONV_TUNE ("bn,tap_inner,halo,dma"); tools/conv_tune.py and the variant-forcing parity tests change them
-// through yolo_conv_tune_set.  Not part of the training path: nothing there writes them.
-struct ConvTune { int bn, tap_inner, halo, dma; };
-static ConvTune& conv_tune() {
+ConvTune& conv_tune() {
     static ConvTune t = [] {
-        ConvTune v{0, -1, -1, -1};
-        if (const char* e = getenv("YOLO_CONV_TUNE")) sscanf(e, "%d,%d,%d,%d", &v.bn, &v.tap_inner, &v.halo, &v.dma);
+        ConvTune v{0, -1, -1, -1, -1, 0, 0, 0};
+        if (const char* e = getenv("YOLO_CONV_TUNE"))
+            sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &v.bn, &v.tap_inner, &v.halo, &v.dma, &v.ring, &v.bm, &v.nst, &v.bk);
         return v;
     }();
     return t;
 }
+
+int ring_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst);
+int ring_conv_plan(const ConvGeom* gs, int n);
+int ring_conv_launch(const ConvGeom* gs, int n, const long* wm_off, long wm_elems, const void* src, const void* wm,
+                     const float* bias, void* dst, int accumulate, int dtype, hipStream_t st);
+
 namespace {
 
 // MODE 0: K walked tap-major (k = tap*Cs + ch), any Cs % 8 == 0; each lane tracks its own (tap, ch).
@@ -489,9 +492,9 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-extern "C" int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma) {
+extern "C" int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma, int ring, int bm, int nst, int bk) {
     ConvTune& t = conv_tune();
-    t.bn = bn; t.tap_inner = tap_inner; t.halo = halo; t.dma = dma;
+    t.bn = bn; t.tap_inner = tap_inner; t.halo = halo; t.dma = dma; t.ring = ring; t.bm = bm; t.nst = nst; t.bk = bk;
     return YOLO_OK;
 }
 
@@ -522,8 +525,10 @@ static int halo_variant(const ConvGeom& g) {
     return 0;
 }
 
-int mfma_conv_plan(const ConvGeom& g) {
+int mfma_conv_plan(const ConvGeom& g, int dtype) {
+    static const long long dummy[2] = {0, 0};
     if (const int hv = halo_variant(g)) return 2000 + hv;
+    if (ring_conv_eligible(g, dtype, dummy, dummy, dummy)) return ring_conv_plan(&g, 1);
     return 1000 + conv_tile_bn(to_dev(g));
 }
 
@@ -531,6 +536,10 @@ int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const f
                      int dtype, hipStream_t st) {
     if ((long)g.N * g.Hg * g.Wg == 0) return YOLO_OK;
     if (const int hv = halo_variant(g)) return halo_conv_launch(g, hv, src, wm, bias, dst, accumulate, dtype, st);
+    if (ring_conv_eligible(g, dtype, src, wm, dst)) {
+        const long off0 = 0;
+        return ring_conv_launch(&g, 1, &off0, (long)g.Cd * g.Kpad, src, wm, bias, dst, accumulate, dtype, st);
+    }
     GeomDev d = to_dev(g);
     if (dtype == YOLO_BF16) launch_conv_t<bf16_t>(d, src, wm, bias, dst, accumulate, st);
     else launch_conv_t<f16_t>(d, src, wm, bias, dst, accumulate, st);

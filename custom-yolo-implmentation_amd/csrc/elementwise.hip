@@ -73,6 +73,28 @@ __global__ void k_copy_channels(const T* __restrict__ src, int lds_, T* __restri
     }
 }
 
+// dst = sum of up to four channel-slice tensors (fp32 accumulate, one rounding): the gradient of a tensor with several
+// consumers in ONE pass (autograd's own accumulation is one ATen add -- three passes over memory -- per extra consumer)
+struct AddSrcs { const void* p[4]; int ld[4]; };
+template <typename T, int V, int NS>
+__global__ void k_add_n(AddSrcs s, T* __restrict__ dst, int ldd, long npix, int cv) {
+    long total = npix * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / cv;
+        int cg = (int)(i - p * cv);
+        float a[V];
+        load_pack<T, V>((const T*)s.p[0] + p * s.ld[0] + cg * V, a);
+#pragma unroll
+        for (int k = 1; k < NS; ++k) {
+            float b[V];
+            load_pack<T, V>((const T*)s.p[k] + p * s.ld[k] + cg * V, b);
+#pragma unroll
+            for (int j = 0; j < V; ++j) a[j] += b[j];
+        }
+        store_pack<T, V>(dst + p * ldd + cg * V, a);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-channel reductions over pixels: partial[blk][2][C]
 //   MODE 0: (sum y, sum y^2)                      -- BN batch statistics / bias gradient
@@ -809,6 +831,28 @@ int yolo_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, long 
             else
                 hipLaunchKernelGGL((k_copy_channels<T, V, false>), dim3(g), dim3(TPB), 0, st, (const T*)src, ld_src,
                                    (T*)dst, ld_dst, npix, cv);
+        });
+    });
+    return YOLO_LAUNCH_CHECK();
+}
+
+// dst[p][c] = src0 + src1 (+ src2 (+ src3)); every operand an NHWC channel slice with its own row stride; dst may be one
+// of the sources.  Replaces autograd's gradient accumulation at fan-out points (model_blocks.py:62,92,156,223-224, neck.py:41-44)
+int yolo_add_n(const void* s0, int ld0, const void* s1, int ld1, const void* s2, int ld2, const void* s3, int ld3, int nsrc,
+               void* dst, int ld_dst, long npix, int C, int dtype, hipStream_t st) {
+    if (nsrc < 2 || nsrc > 4 || npix <= 0) return nsrc >= 2 && nsrc <= 4 ? YOLO_OK : YOLO_ERR_ARG;
+    AddSrcs a;
+    a.p[0] = s0; a.p[1] = s1; a.p[2] = s2; a.p[3] = s3;
+    a.ld[0] = ld0; a.ld[1] = ld1; a.ld[2] = ld2; a.ld[3] = ld3;
+    YOLO_DISPATCH_T(dtype, {
+        bool ok = vec_ok<T>(dst, ld_dst, C);
+        for (int k = 0; k < nsrc; ++k) ok = ok && vec_ok<T>(a.p[k], a.ld[k], C);
+        PICK_V(T, ok, {
+            int cv = C / V;
+            int g = ew_grid(npix * cv);
+            if (nsrc == 2) hipLaunchKernelGGL((k_add_n<T, V, 2>), dim3(g), dim3(TPB), 0, st, a, (T*)dst, ld_dst, npix, cv);
+            else if (nsrc == 3) hipLaunchKernelGGL((k_add_n<T, V, 3>), dim3(g), dim3(TPB), 0, st, a, (T*)dst, ld_dst, npix, cv);
+            else hipLaunchKernelGGL((k_add_n<T, V, 4>), dim3(g), dim3(TPB), 0, st, a, (T*)dst, ld_dst, npix, cv);
         });
     });
     return YOLO_LAUNCH_CHECK();

@@ -171,6 +171,36 @@ class Alias(torch.autograd.Function):
         return g
 
 
+class Fanout(torch.autograd.Function):
+    """x handed to k consumers as k aliases: autograd delivers the k gradients TOGETHER and they are summed by one HIP
+    pass (ops.add_n: fp32 accumulate, one rounding) instead of k-1 ATen adds of three memory passes each."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        return tuple(_fresh(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        T = gs[0].dtype
+        gs = [_as_nhwc(g, T) for g in gs]
+        acc = ops.add_n(gs[:4])
+        for i in range(4, len(gs), 3):
+            acc = ops.add_n([acc] + gs[i:i + 3])
+        return acc, None
+
+
+def fanout(x, k):
+    """k handles on x for k consumers (see Fanout); plain references when no gradient will flow."""
+    if k < 2 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * k
+    return Fanout.apply(x, k)
+
+
 class ConvBnAct(torch.autograd.Function):
     """act(BN(conv(x))) (+ residual).  Reference: Conv.forward, src/model/model_blocks.py:31-34; the
     residual adds of Residual/PSABlock (:62, :223-224) ride in the same epilogue.

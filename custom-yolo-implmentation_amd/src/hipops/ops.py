@@ -106,6 +106,19 @@ def copy_channels(src, dst, accumulate=False):
     lib.call("yolo_copy_channels", _p(src), lds, _p(dst), ldd, n * h * w, c, int(accumulate), dt(src), _stream(src))
 
 
+def add_n(xs, out=None):
+    """Sum of 2..4 same-shaped NHWC tensors (channel slices allowed) in one pass -> fresh NHWC tensor (or `out`)."""
+    n, c, h, w, _ = geom(xs[0])
+    out = _dest(out, n, c, h, w, xs[0].dtype, xs[0].device)
+    g = [geom(x) for x in xs]
+    assert all(gi[:4] == (n, c, h, w) for gi in g) and all(x.dtype == xs[0].dtype for x in xs) and 2 <= len(xs) <= 4
+    ptr = [_p(x) for x in xs] + [0] * (4 - len(xs))
+    ld = [gi[4] for gi in g] + [0] * (4 - len(xs))
+    lib.call("yolo_add_n", ptr[0], ld[0], ptr[1], ld[1], ptr[2], ld[2], ptr[3], ld[3], len(xs), _p(out), geom(out)[4],
+             n * h * w, c, dt(xs[0]), _stream(xs[0]))
+    return out
+
+
 def zero_(t):
     lib.call("yolo_memset0", _p(t), t.numel() * t.element_size(), _stream(t))
     return t

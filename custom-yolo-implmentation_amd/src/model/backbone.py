@@ -4,6 +4,7 @@ from typing import List
 
 from torch import nn
 
+from src.hipops import functions as F_
 from src.model.model_blocks import C3K2, PSA, SPPF, Conv
 
 
@@ -23,6 +24,6 @@ class Backbone(nn.Module):
                                 SPPF(w[5], w[5]), PSA(w[5], depth[4]))
 
     def forward(self, x):
-        p3 = self.p3(self.p2(self.p1(x)))
-        p4 = self.p4(p3)
-        return p3, p4, self.p5(p4)
+        p3, p3n = F_.fanout(self.p3(self.p2(self.p1(x))), 2)      # one handle per consumer: next stage, neck
+        p4, p4n = F_.fanout(self.p4(p3n), 2)
+        return p3, p4, self.p5(p4n)

@@ -46,7 +46,7 @@ class Conv(nn.Module):
         return F_.ConvBnAct.apply(x, self.conv.weight, n.weight, n.bias, residual, (n.running_mean, n.running_var),
                                   self._k, self._s, self._dw, self._act, self.training, n.momentum, n.eps, out, res_link)
 
-    def fuse_forward(self, x, residual=None, out=None):
+    def fuse_forward(self, x, residual=None, out=None, res_link=None):
         return F_.fused_conv_act(x, self.conv.weight, self.conv.bias, self._k, self._s, self._dw, self._act, residual, out)
 
 
@@ -83,8 +83,9 @@ class C3K(nn.Module):
         # both branches write their half of the concat buffer directly (no torch.cat copy)
         half = self.conv1.conv.out_channels
         buf = F_.cat_buffer(x, self.conv1.conv.weight, 2 * half)
-        a = self.res_m[1](self.res_m[0](self.conv1(x)), out=buf[:, :half])
-        b = self.conv2(x, out=buf[:, half:])
+        x1, x2 = F_.fanout(x, 2)
+        a = self.res_m[1](self.res_m[0](self.conv1(x1)), out=buf[:, :half])
+        b = self.conv2(x2, out=buf[:, half:])
         return self.conv3(F_.CatInto.apply(buf, a, b), out=out)
 
 
@@ -125,10 +126,10 @@ class SPPF(nn.Module):
     def forward(self, x):
         c = self.cv1.conv.out_channels
         buf = F_.cat_buffer(x, self.cv1.conv.weight, 4 * c)
-        x = self.cv1(x, out=buf[:, :c])
-        y1 = F_.MaxPool5.apply(x, buf[:, c:2 * c])
-        y2 = F_.MaxPool5.apply(y1, buf[:, 2 * c:3 * c])
-        y3 = F_.MaxPool5.apply(y2, buf[:, 3 * c:])
+        x, xp = F_.fanout(self.cv1(x, out=buf[:, :c]), 2)                 # each map feeds the concat and the next pool
+        y1, y1p = F_.fanout(F_.MaxPool5.apply(xp, buf[:, c:2 * c]), 2)
+        y2, y2p = F_.fanout(F_.MaxPool5.apply(y1p, buf[:, 2 * c:3 * c]), 2)
+        y3 = F_.MaxPool5.apply(y2p, buf[:, 3 * c:])
         return self.cv2(F_.CatInto.apply(buf, x, y1, y2, y3))
 
 
@@ -146,9 +147,11 @@ class Attention(nn.Module):
         self.conv1 = Conv(ch, ch, nn.Identity(), k=3, p=1, g=ch)
         self.conv2 = Conv(ch, ch, nn.Identity())
 
-    def forward(self, x, residual=None):
-        o, v = F_.AttentionCore.apply(self.qkv(x), self.num_head, self.dim_key, self.dim_head, self.scale)
-        return self.conv2(self.conv1(v, o), residual)        # conv2(attn_out + dwconv(v)) (+ x)
+    def forward(self, x, residual=None, res_link=None):
+        """`res_link` (F_.ResLink, with residual = the SAME alias as x): the qkv conv's data gradient is accumulated
+        into the residual gradient conv2's backward leaves in the link."""
+        o, v = F_.AttentionCore.apply(self.qkv(x, res_link=res_link), self.num_head, self.dim_key, self.dim_head, self.scale)
+        return self.conv2(self.conv1(v, o), residual, res_link=res_link)        # conv2(attn_out + dwconv(v)) (+ x)
 
 
 class PSABlock(nn.Module):
@@ -160,8 +163,15 @@ class PSABlock(nn.Module):
         self.conv2 = nn.Sequential(Conv(ch, ch * 2, nn.SiLU()), Conv(ch * 2, ch, nn.Identity()))
 
     def forward(self, x):
-        x = self.conv1(x, x)
-        return self.conv2[1](self.conv2[0](x), x)
+        if not (self.training and torch.is_grad_enabled()):
+            x = self.conv1(x, x)
+            return self.conv2[1](self.conv2[0](x), x)
+        # both residual sums as in Residual: the first consumer's data gradient is accumulated into the residual
+        # gradient by its own kernel epilogue (F_.ResLink) instead of an extra add pass
+        xp, link = F_.Alias.apply(x), F_.ResLink()
+        x = self.conv1(xp, xp, res_link=link)
+        xp, link = F_.Alias.apply(x), F_.ResLink()
+        return self.conv2[1](self.conv2[0](xp, res_link=link), xp, res_link=link)
 
 
 class PSA(nn.Module):

@@ -31,8 +31,10 @@ class Neck(nn.Module):
             first = make_first[0](buf[:, :c1])
             return head(F_.CatInto.apply(buf, first, skip))
 
-        p4 = joined(self.h1, (lambda o: F_.Upsample2x.apply(p5, o), p5.shape[1]), p4)
-        p3 = joined(self.h2, (lambda o: F_.Upsample2x.apply(p4, o), p4.shape[1]), p3)
-        p4 = joined(self.h4, (lambda o: self.h3(p3, out=o), self.h3.conv.out_channels), p4)
-        p5 = joined(self.h6, (lambda o: self.h5(p4, out=o), self.h5.conv.out_channels), p5)
-        return p3, p4, p5
+        # every tensor with two consumers goes out as two handles (F_.Fanout: its gradients are summed in one pass)
+        p5u, p5s = F_.fanout(p5, 2)
+        p4u, p4s = F_.fanout(joined(self.h1, (lambda o: F_.Upsample2x.apply(p5u, o), p5.shape[1]), p4), 2)
+        p3o, p3d = F_.fanout(joined(self.h2, (lambda o: F_.Upsample2x.apply(p4u, o), p4.shape[1]), p3), 2)
+        p4o, p4d = F_.fanout(joined(self.h4, (lambda o: self.h3(p3d, out=o), self.h3.conv.out_channels), p4s), 2)
+        p5o = joined(self.h6, (lambda o: self.h5(p4d, out=o), self.h5.conv.out_channels), p5s)
+        return p3o, p4o, p5o

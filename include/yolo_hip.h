@@ -44,6 +44,8 @@ int yolo_ncm_to_nhwc(const void* src, int src_dtype, long sn, long sc, long off,
 int yolo_nhwc_to_ncm(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, long sn, long sc, long off, int N, int C, int HW, hipStream_t st);
 int yolo_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, long npix, int C, int accumulate, int dtype, hipStream_t st);
 int yolo_scale_inplace(void* x, long n, int dtype, const float* scale_dev, hipStream_t st);
+/* gradient fan-in: dst = sum of 2..4 channel-slice tensors in one pass (autograd's accumulation where a tensor has several consumers: model_blocks.py:62,92,156,223-224, neck.py:41-44, head.py:87) */
+int yolo_add_n(const void* s0, int ld0, const void* s1, int ld1, const void* s2, int ld2, const void* s3, int ld3, int nsrc, void* dst, int ld_dst, long npix, int C, int dtype, hipStream_t st);
 
 /* ---- convolution (nn.Conv2d: model_blocks.py:27, head.py:50,60; its autograd dgrad/wgrad) */
 int yolo_conv_kpad(int O, int I, int k, int stride, int mode, int cls);
@@ -69,11 +71,13 @@ long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy,
 int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws, void* dw_oihw, int dw_dtype, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 /* kernel-selection overrides for tuning runs (tools/conv_tune.py, tools/wg_tune.py) and the variant-forcing parity tests
    (tests/test_gpu_conv_variants.py); process-wide, 0 / -1 = automatic; the training path never calls them.
-   conv: bn in {0, 32, 64, 128}, tap_inner / dma in {-1, 0, 1}, halo in {-1, 0 (gather kernel), 1..4}.  No reference counterpart (model_blocks.py:27). */
-int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma);
+   conv: bn in {0, 32, 64, 128}, tap_inner / dma in {-1, 0, 1}, halo in {-1, 0 (gather kernel), 1..4}, ring in {-1, 0 (off), 1},
+   bm in {0, 64, 128}, nst in {0, 2, 3, 4} and bk in {0, 32, 64} (ring kernel's pixel tile, ring depth and K-step).  No reference counterpart (model_blocks.py:27). */
+int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma, int ring, int bm, int nst, int bk);
 int yolo_wgrad_tune_set(int to, int ti, int blocks, int min_per);
 /* which kernel a forward (mode 0) / data-gradient (mode 1, parity class cls for stride 2) launch of this shape takes:
-   kind * 1000 + width, kind 1 = gather MFMA kernel (width = channel tile 32/64/128), 2 = halo MFMA kernel (width = variant 1..4), 0 = VALU kernels */
+   kind * 1000 + width, kind 1 = gather MFMA kernel (width = channel tile 32/64/128), 2 = halo MFMA kernel (width = variant 1..4),
+   3 = pipelined ring kernel (width = channel tile, + 500 for 64-pixel tiles), 0 = VALU kernels */
 int yolo_conv2d_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int mode, int cls, int dtype);
 /* weight-gradient plan of a shape: to * 1000000 + ti * 100000 + nslab (MFMA path), 0 = other paths */
 long yolo_conv2d_wgrad_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype);

@@ -36,7 +36,7 @@ def lib():
 def _reset_tuning():
     torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
     yield
-    lib().call("yolo_conv_tune_set", 0, -1, -1, -1)
+    lib().call("yolo_conv_tune_set", 0, -1, -1, -1, -1, 0, 0, 0)
     lib().call("yolo_wgrad_tune_set", 0, 0, 0, 0)
 
 
@@ -146,21 +146,34 @@ def run_wgrad_case(n, cin, cout, h, w, k, s, ldx=None, ldy=None, seed=0):
 @pytest.mark.parametrize("dma", [0, 1])
 @pytest.mark.parametrize("cin,cout,k,s", [(64, 128, 3, 1), (96, 200, 1, 1), (64, 64, 3, 2), (32, 136, 3, 1)])
 def test_gather_kernel_every_tile_width_and_staging_mode(bn, dma, cin, cout, k, s):
-    lib().call("yolo_conv_tune_set", bn, -1, 0, dma)
+    lib().call("yolo_conv_tune_set", bn, -1, 0, dma, 0, 0, 0, 0)
     run_fwd_dgrad_case(3, cin, cout, 37, 41, k, s, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=1000 + bn,
                        seed=bn + dma)
 
 
 @pytest.mark.parametrize("bn", [64, 128])
 def test_gather_kernel_tap_inner_order(bn):
-    lib().call("yolo_conv_tune_set", bn, 1, 0, 1)
+    lib().call("yolo_conv_tune_set", bn, 1, 0, 1, 0, 0, 0, 0)
     run_fwd_dgrad_case(2, 64, 128, 23, 29, 3, 1, images=[0, 1], want_plan=1000 + bn, seed=7)
+
+
+@pytest.mark.parametrize("bk,bm,bn", [(64, 128, 128), (64, 128, 64), (64, 64, 128), (64, 64, 64), (64, 128, 32),
+                                      (32, 128, 128), (32, 128, 64), (32, 64, 128), (32, 64, 64)])
+@pytest.mark.parametrize("nst", [2, 3, 4])
+@pytest.mark.parametrize("cin,cout,k,s", [(64, 128, 3, 1), (96, 200, 1, 1), (64, 64, 3, 2), (160, 136, 3, 1), (128, 72, 3, 2)])
+def test_ring_kernel_every_tile_and_depth(bk, bm, bn, nst, cin, cout, k, s):
+    """The pipelined ring kernel: every tile shape and K-step at every ring depth; channel counts that are not multiples
+    of the 64-deep K-step (96, 160: partial last chunk step) or of the channel tile (200, 136, 72); stride-2 data
+    gradients (four parity classes in one launch, odd map: the classes differ in size); partial last pixel tile."""
+    lib().call("yolo_conv_tune_set", bn, -1, 0, -1, 1, bm, nst, bk)
+    run_fwd_dgrad_case(3, cin, cout, 37, 41, k, s, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16,
+                       want_plan=3000 + (500 if bm == 64 else 0) + bn, seed=bm + bn + nst)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64), (96, 192)])
 def test_halo_kernel_every_variant(variant, cin, cout):
-    lib().call("yolo_conv_tune_set", 0, -1, variant, -1)
+    lib().call("yolo_conv_tune_set", 0, -1, variant, -1, -1, 0, 0, 0)
     run_fwd_dgrad_case(3, cin, cout, 37, 41, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=2000 + variant,
                        seed=variant)
 
@@ -256,7 +269,7 @@ def test_config2_forward_and_dgrad_calls_elementwise(config2_calls):
     print(f"\n[config-2 conv calls] {len(shapes)} distinct shapes, forward plans (kind*1000+width -> count): {plans}")
     assert not failures, "\n".join(failures)
     # the step must have exercised the wide tiles and the halo kernel (what the bench's time is made of)
-    assert any(p in plans for p in (1064, 1128)) and any(p // 1000 == 2 for p in plans), plans
+    assert any(p // 1000 == 3 for p in plans) and any(p // 1000 == 2 for p in plans), plans
 
 
 def test_config2_weight_gradient_calls_elementwise(config2_calls):
@@ -282,7 +295,7 @@ def test_stride2_dgrad_real_shape_all_parity_classes():
     """128 -> 128 3x3 stride 2 on a 160 x 160 map, 32 images (the biggest conv of preset s): four parity-class launches."""
     q = lib().query
     got = [q("yolo_conv2d_plan", 32, 160, 160, 128, 80, 80, 128, 3, 2, 1, c, lib().BF16) for c in range(4)]
-    assert all(g // 1000 == 1 for g in got), got
+    assert all(g // 1000 == 3 for g in got), got
     run_fwd_dgrad_case(32, 128, 128, 160, 160, 3, 2, images=[0, 17, 31], stats=True, acc=(False, True), seed=77)
     # odd map: the parity classes have different sizes
     run_fwd_dgrad_case(2, 64, 64, 45, 39, 3, 2, images=[0, 1], stats=False, seed=78)

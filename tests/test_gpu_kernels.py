@@ -91,6 +91,19 @@ def test_copy_channels(dtype, c, pad):
         check(d_gpu, d_cpu, dtype, f"copy_channels acc={acc}")
 
 
+@pytest.mark.parametrize("dtype,c,pad,k", [(torch.float32, 12, 4, 2), (torch.bfloat16, 16, 16, 3), (torch.bfloat16, 24, 8, 4),
+                                           (torch.float16, 6, 3, 2)])
+def test_add_n_gradient_fan_in(dtype, c, pad, k):
+    """sum of k channel-slice tensors in one pass (fp32 accumulate, one rounding) == the stand-in's fp32 sum"""
+    o = ops()
+    xs = [nhwc(rnd(2, c, 5, 7, seed=4 + i).to(dtype), pad if i % 2 else 0) for i in range(k)]
+    got = o.add_n([dev(x) for x in xs])
+    check(got, emu.add_n(xs), dtype, f"add_n k={k}")
+    into = dev(nhwc(rnd(2, c, 5, 7, seed=99).to(dtype), pad))
+    o.add_n([dev(x) for x in xs], out=into)
+    check(into, emu.add_n(xs), dtype, f"add_n k={k} into a slice")
+
+
 # ------------------------------------------------------------------------------------------ convolution
 CONV_CASES = [  # cin, cout, h, w, k, s, pad_c
     (3, 16, 17, 19, 3, 2, 0), (16, 32, 12, 12, 1, 1, 0), (16, 16, 13, 11, 3, 1, 16), (32, 64, 16, 16, 3, 2, 0),

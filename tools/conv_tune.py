@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "custom-yolo-implmentation_amd"))
 import torch
 from src.hipops import lib, ops
 
-def tune(bn=0, tap_inner=-1, halo=-1, dma=-1):
-    lib.call("yolo_conv_tune_set", bn, tap_inner, halo, dma)
+def tune(bn=0, tap_inner=-1, halo=-1, dma=-1, ring=0, bm=0, nst=0, bk=0):
+    lib.call("yolo_conv_tune_set", bn, tap_inner, halo, dma, ring, bm, nst, bk)
 
 def timeit(fn, secs=0.15):
     for _ in range(3): fn()
