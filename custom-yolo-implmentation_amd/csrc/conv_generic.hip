@@ -150,7 +150,7 @@ __global__ void k_unpack_wgrad(const float* __restrict__ dwp, int O, int I, int 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int V, bool FLIP>
 __global__ void k_dw3x3(const T* __restrict__ x, int ldx, const float* __restrict__ w, T* __restrict__ y, int ldy,
-                        int N, int H, int W, int C) {
+                        int N, int H, int W, int C, int accumulate) {
     // row-strided: a thread owns one channel group (its 9 x V taps live in registers), a workgroup walks
     // image rows, threads of one group stride along the row -- no per-element index division
     const int cv = C / V;
@@ -183,6 +183,12 @@ __global__ void k_dw3x3(const T* __restrict__ x, int ldx, const float* __restric
 #pragma unroll
                     for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], wt[kh * 3 + kw][j], acc[j]);
                 }
+            }
+            if (accumulate) {                             // gradient fan-in: add to what another consumer's backward left
+                float o[V];
+                load_pack<T, V>(y + ((long)row * W + ww) * ldy + cg * V, o);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += o[j];
             }
             store_pack<T, V>(y + ((long)row * W + ww) * ldy + cg * V, acc);
         }
@@ -548,15 +554,15 @@ static dim3 dw_grid(int nrows, int cv) {
 
 template <bool FLIP>
 static int dw_launch(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
-                     hipStream_t st) {
+                     int accumulate, hipStream_t st) {
     YOLO_DISPATCH_T(dtype, {
         if (vecok<T>(x, ldx, C) && vecok<T>(y, ldy, C)) {
             constexpr int V = vec_of<T>::N;
             hipLaunchKernelGGL((k_dw3x3<T, V, FLIP>), dw_grid(N * H, C / V), dim3(256), 0, st, (const T*)x, ldx, w, (T*)y,
-                               ldy, N, H, W, C);
+                               ldy, N, H, W, C, accumulate);
         } else {
             hipLaunchKernelGGL((k_dw3x3<T, 1, FLIP>), dw_grid(N * H, C), dim3(256), 0, st, (const T*)x, ldx, w, (T*)y, ldy,
-                               N, H, W, C);
+                               N, H, W, C, accumulate);
         }
     });
     return YOLO_LAUNCH_CHECK();
@@ -566,12 +572,12 @@ extern "C" {
 
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
                        hipStream_t st) {
-    return dw_launch<false>(x, ldx, w, y, ldy, N, H, W, C, dtype, st);
+    return dw_launch<false>(x, ldx, w, y, ldy, N, H, W, C, dtype, 0, st);
 }
 
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C,
-                         int dtype, hipStream_t st) {
-    return dw_launch<true>(dy, lddy, w, dx, lddx, N, H, W, C, dtype, st);
+                         int accumulate, int dtype, hipStream_t st) {
+    return dw_launch<true>(dy, lddy, w, dx, lddx, N, H, W, C, dtype, accumulate, st);
 }
 
 // number of row slabs (= partial blocks) yolo_dwconv3x3_wgrad uses for an (N, H) map

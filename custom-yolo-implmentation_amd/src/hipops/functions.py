@@ -152,23 +152,75 @@ class ResLink:
     """Shared by the two convs of x + conv2(conv1(x)): conv2's backward leaves the residual gradient here and conv1's
     data gradient is ADDED to it in its kernel epilogue, instead of autograd summing two tensors with one more pass
     over them.  Safe only if nothing else consumes x between the two: Residual wraps its input in `Alias`, whose only
-    consumers are those two convs."""
-    __slots__ = ("dres",)
+    consumers are those two convs.
 
-    def __init__(self):
+    `fan=True` (see `fan2`) makes the protocol symmetric for ANY two consumers of an alias: whichever backward runs
+    first leaves its gradient in `dres` (and returns it to autograd), the second ADDS its own into that tensor in its
+    kernel epilogue and returns None -- autograd never sums, no extra pass over the gradient."""
+    __slots__ = ("dres", "fan")
+
+    def __init__(self, fan=False):
         self.dres = None
+        self.fan = fan
+
+    def usable(self, shape, dtype):
+        """The gradient left by the first consumer, if the second can accumulate into it."""
+        d = self.dres
+        if d is None or tuple(d.shape) != tuple(shape) or d.dtype != dtype or not ops.is_nhwc(d):
+            return None
+        return d
 
 
 class Alias(torch.autograd.Function):
-    """The same tensor under a new autograd node: consumers of the alias are the alias' only consumers."""
+    """The same tensor under a new autograd node: consumers of the alias are the alias' only consumers.  With a link,
+    the node (which runs after both consumers' backward) clears it: a second backward over a retained graph starts clean."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, link=None):
+        ctx.link = link
         return _fresh(x)
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        if ctx.link is not None:
+            ctx.link.dres = None
+        return g, None
+
+
+class Stash(torch.autograd.Function):
+    """Handle on an alias for a consumer that has no accumulating epilogue of its own (a concat slice, another fan-out):
+    its gradient goes into the link for the other consumer to add to; if the other consumer came first, it is added to
+    that one here (one HIP pass)."""
+
+    @staticmethod
+    def forward(ctx, x, link):
+        ctx.link = link
+        return _fresh(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        link = ctx.link
+        g = _as_nhwc(g, g.dtype)
+        first = link.usable(g.shape, g.dtype)
+        if first is None:
+            link.dres = g
+            return g, None
+        ops.copy_channels(g, first, accumulate=True)
+        return None, None
+
+
+def fan2(x):
+    """(alias of x, link) for exactly TWO consumers of the alias that each take the link: `conv(alias, res_link=link)`,
+    `Upsample2x / MaxPool5 .apply(alias, out, link)`, or `Stash.apply(alias, link)` for anything else.  Without a gradient
+    to propagate: (x, None)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, None
+    link = ResLink(fan=True)
+    return Alias.apply(x, link), link
+
+
+def stash(x, link):
+    return x if link is None else Stash.apply(x, link)
 
 
 class Fanout(torch.autograd.Function):
@@ -305,7 +357,13 @@ class ConvBnAct(torch.autograd.Function):
                     dw = stem_dw()
         elif depthwise:
             if ctx.needs_input_grad[0]:
-                dx = ops.dw_dgrad(dy, _f32(weight).reshape(weight.shape[0], 9))
+                link = ctx.res_link if (ctx.res_link is not None and ctx.res_link.fan and not has_res) else None
+                into = link.usable((n, cin, h, w), T) if link is not None else None
+                dx = ops.dw_dgrad(dy, _f32(weight).reshape(weight.shape[0], 9), acc_into=into)
+                if into is not None:
+                    dx = None                                   # already inside the gradient the first consumer returned
+                elif link is not None:
+                    link.dres = dx
             if ctx.needs_input_grad[1]:
                 if weight.dtype == torch.float32 and x.is_cuda and LAZY_WGRAD_JOIN:
                     dwb = torch.empty((weight.shape[0], 1, 3, 3), dtype=torch.float32, device=x.device)
@@ -317,13 +375,16 @@ class ConvBnAct(torch.autograd.Function):
                     dw = ops.dw_wgrad(x, dy).to(weight.dtype)
         else:
             link = ctx.res_link if not has_res else None
-            into = link.dres if link is not None else None          # the residual gradient conv2's backward left
-            if into is not None and (tuple(into.shape) != (n, cin, h, w) or into.dtype != T or not ops.is_nhwc(into)):
-                into = None
+            # the residual gradient conv2's backward left / the gradient the alias' other consumer left (fan link)
+            into = link.usable((n, cin, h, w), T) if link is not None else None
 
             def dgrad():
                 r = ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride, acc_into=into)
-                return None if into is not None else r      # already inside the gradient autograd holds for x
+                if into is not None:
+                    return None                             # already inside the gradient autograd holds for x
+                if link is not None and link.fan:
+                    link.dres = r                           # first of the two consumers: the other adds to this
+                return r
             if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
                 dx, dw = _wgrad_overlapped(x, dy, k, stride, weight.dtype, dgrad)
             elif ctx.needs_input_grad[0]:
@@ -335,7 +396,7 @@ class ConvBnAct(torch.autograd.Function):
         else:
             dgamma = dbeta = None
         dres = dout if (has_res and ctx.needs_input_grad[4]) else None
-        if has_res and ctx.res_link is not None:
+        if has_res and ctx.res_link is not None and not ctx.res_link.fan:
             ctx.res_link.dres = dres
         return dx, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
@@ -437,6 +498,19 @@ class Cat(torch.autograd.Function):
         return tuple(grads)
 
 
+def _fan_bwd(link, shape, dtype, run):
+    """Gradient of one of the two consumers of a fan2 alias: `run(acc_into)` computes it, added to the other consumer's
+    gradient when that one came first (returns None: nothing for autograd to add), else left in the link."""
+    if link is None:
+        return run(None)
+    into = link.usable(shape, dtype)
+    g = run(into)
+    if into is not None:
+        return None
+    link.dres = g
+    return g
+
+
 def _fresh(t):
     """A Function output must not BE one of its inputs: hand back a new tensor object on the same memory
     (the caller's `out=` view) so autograd attaches the node to it without view / in-place bookkeeping."""
@@ -523,27 +597,32 @@ class MaxPool5(torch.autograd.Function):
     """nn.MaxPool2d(5, 1, 2) (src/model/model_blocks.py:150)."""
 
     @staticmethod
-    def forward(ctx, x, out=None):
+    def forward(ctx, x, out=None, link=None):
         out, idx = ops.maxpool5_fwd(_as_nhwc(x, x.dtype), out)
         ctx.save_for_backward(idx)
+        ctx.link = link
         return _fresh(out)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return ops.maxpool5_bwd(_as_nhwc(dout, dout.dtype), idx), None
+        dout = _as_nhwc(dout, dout.dtype)
+        return _fan_bwd(ctx.link, dout.shape, dout.dtype, lambda into: ops.maxpool5_bwd(dout, idx, acc_into=into)), None, None
 
 
 class Upsample2x(torch.autograd.Function):
     """nn.Upsample(scale_factor=2), nearest (src/model/neck.py:31)."""
 
     @staticmethod
-    def forward(ctx, x, out=None):
+    def forward(ctx, x, out=None, link=None):
+        ctx.link = link
         return _fresh(ops.upsample2x_fwd(_as_nhwc(x, x.dtype), out))
 
     @staticmethod
     def backward(ctx, dout):
-        return ops.upsample2x_bwd(_as_nhwc(dout, dout.dtype)), None
+        dout = _as_nhwc(dout, dout.dtype)
+        n, c, oh, ow = dout.shape
+        return _fan_bwd(ctx.link, (n, c, oh // 2, ow // 2), dout.dtype, lambda into: ops.upsample2x_bwd(dout, acc_into=into)), None, None
 
 
 class AttentionCore(torch.autograd.Function):

@@ -346,10 +346,16 @@ def dw_fwd(x, w9):
     return y
 
 
-def dw_dgrad(dy, w9):
+def dw_dgrad(dy, w9, acc_into=None):
+    """Depthwise data gradient; with `acc_into` it is ADDED to that tensor (gradient fan-in) instead of written to a new one."""
     n, c, h, w, ld = geom(dy)
-    dx = new_nhwc(n, c, h, w, dy.dtype, dy.device)
-    lib.call("yolo_dwconv3x3_dgrad", _p(dy), ld, _p(w9), _p(dx), c, n, h, w, c, dt(dy), _stream(dy))
+    if acc_into is None:
+        dx, accumulate = new_nhwc(n, c, h, w, dy.dtype, dy.device), 0
+    else:
+        if tuple(acc_into.shape) != (n, c, h, w) or acc_into.dtype != dy.dtype:
+            raise RuntimeError("dw_dgrad: acc_into does not match the input gradient's shape / dtype")
+        dx, accumulate = acc_into, 1
+    lib.call("yolo_dwconv3x3_dgrad", _p(dy), ld, _p(w9), _p(dx), geom(dx)[4], n, h, w, c, accumulate, dt(dy), _stream(dy))
     return dx
 
 
@@ -452,10 +458,18 @@ def maxpool5_fwd(x, out=None):
     return out, idx
 
 
-def maxpool5_bwd(dout, idx):
+def _acc_dest(acc_into, n, c, h, w, like):
+    if acc_into is None:
+        return new_nhwc(n, c, h, w, like.dtype, like.device), 0
+    if tuple(acc_into.shape) != (n, c, h, w) or acc_into.dtype != like.dtype:
+        raise RuntimeError("acc_into does not match the gradient's shape / dtype")
+    return acc_into, 1
+
+
+def maxpool5_bwd(dout, idx, acc_into=None):
     n, c, h, w, ld = geom(dout)
-    dx = new_nhwc(n, c, h, w, dout.dtype, dout.device)
-    lib.call("yolo_maxpool5_bwd", _p(dout), ld, _p(idx), _p(dx), c, n, h, w, c, 0, dt(dout), _stream(dout))
+    dx, accumulate = _acc_dest(acc_into, n, c, h, w, dout)
+    lib.call("yolo_maxpool5_bwd", _p(dout), ld, _p(idx), _p(dx), geom(dx)[4], n, h, w, c, accumulate, dt(dout), _stream(dout))
     return dx
 
 
@@ -466,10 +480,10 @@ def upsample2x_fwd(x, out=None):
     return out
 
 
-def upsample2x_bwd(dout):
+def upsample2x_bwd(dout, acc_into=None):
     n, c, oh, ow, ld = geom(dout)
-    dx = new_nhwc(n, c, oh // 2, ow // 2, dout.dtype, dout.device)
-    lib.call("yolo_upsample2x_bwd", _p(dout), ld, _p(dx), c, n, oh // 2, ow // 2, c, 0, dt(dout), _stream(dout))
+    dx, accumulate = _acc_dest(acc_into, n, c, oh // 2, ow // 2, dout)
+    lib.call("yolo_upsample2x_bwd", _p(dout), ld, _p(dx), geom(dx)[4], n, oh // 2, ow // 2, c, accumulate, dt(dout), _stream(dout))
     return dx
 
 

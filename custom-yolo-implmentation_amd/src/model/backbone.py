@@ -24,6 +24,15 @@ class Backbone(nn.Module):
                                 SPPF(w[5], w[5]), PSA(w[5], depth[4]))
 
     def forward(self, x):
-        p3, p3n = F_.fanout(self.p3(self.p2(self.p1(x))), 2)      # one handle per consumer: next stage, neck
-        p4, p4n = F_.fanout(self.p4(p3n), 2)
-        return p3, p4, self.p5(p4n)
+        # p3 / p4 feed the next stage (a stride-2 Conv) and the neck: that conv's data gradient is ADDED to the neck's
+        # gradient in its kernel epilogue (F_.fan2) instead of autograd summing the two
+        p3, l3 = F_.fan2(self.p3(self.p2(self.p1(x))))
+        p4, l4 = F_.fan2(self._stage(self.p4, p3, l3))
+        return F_.stash(p3, l3), F_.stash(p4, l4), self._stage(self.p5, p4, l4)
+
+    @staticmethod
+    def _stage(seq, x, link):
+        x = seq[0](x, res_link=link)
+        for m in seq[1:]:
+            x = m(x)
+        return x

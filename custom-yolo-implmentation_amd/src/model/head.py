@@ -42,15 +42,18 @@ class Head(nn.Module):
             nn.init.constant_(branch[-1].bias, b)
 
     @staticmethod
-    def _branch(seq, x):
-        for m in seq[:-1]:
+    def _branch(seq, x, link=None):
+        x = seq[0](x, res_link=link)
+        for m in seq[1:-1]:
             x = m(x)
         last = seq[-1]
         return F_.ConvBias.apply(x, last.weight, last.bias, 1, 1)
 
     def forward(self, x):
-        pairs = [F_.fanout(t, 2) for t in x]                 # a level feeds its box and its class branch
-        xb, xc = [p[0] for p in pairs], [p[1] for p in pairs]
+        # a level feeds its box and its class branch: the second branch's data gradient is added to the first's (F_.fan2)
+        pairs = [F_.fan2(t) for t in x]
+        xb = xc = [p[0] for p in pairs]
+        links = [p[1] for p in pairs]
         hooked = any(m._forward_hooks or m._forward_pre_hooks for m in self.cls.modules())    # a user hook would read a
         if self.training and x[0].is_cuda and F_.HEAD_TWO_STREAMS and torch.is_grad_enabled() and not hooked:    # side-stream tensor unsynchronised
             # forward of the class branches on the auxiliary stream, beside the box branches (one fork, one join).
@@ -62,16 +65,16 @@ class Head(nn.Module):
             side.wait_stream(cur)
             F_.FWD_STREAM = side
             try:
-                cls_outs = [self._branch(self.cls[i], xc[i]) for i in range(self.nl)]
+                cls_outs = [self._branch(self.cls[i], xc[i], links[i]) for i in range(self.nl)]
             finally:
                 F_.FWD_STREAM = None
-            box_outs = [self._branch(self.box[i], xb[i]) for i in range(self.nl)]
+            box_outs = [self._branch(self.box[i], xb[i], links[i]) for i in range(self.nl)]
             cur.wait_stream(side)
             outs = [o for pair in zip(box_outs, cls_outs) for o in pair]
         else:
             outs = []
             for i in range(self.nl):
-                outs += [self._branch(self.box[i], xb[i]), self._branch(self.cls[i], xc[i])]
+                outs += [self._branch(self.box[i], xb[i], links[i]), self._branch(self.cls[i], xc[i], links[i])]
         preds = F_.HeadPack.apply(*outs)
         shapes = tuple((int(o.shape[2]), int(o.shape[3])) for o in outs[::2])
         anchors, strides = make_anchors_cached(shapes, tuple(float(s) for s in self.stride), preds.dtype, preds.device)

@@ -83,9 +83,9 @@ class C3K(nn.Module):
         # both branches write their half of the concat buffer directly (no torch.cat copy)
         half = self.conv1.conv.out_channels
         buf = F_.cat_buffer(x, self.conv1.conv.weight, 2 * half)
-        x1, x2 = F_.fanout(x, 2)
-        a = self.res_m[1](self.res_m[0](self.conv1(x1)), out=buf[:, :half])
-        b = self.conv2(x2, out=buf[:, half:])
+        xa, link = F_.fan2(x)                                 # two 1x1 convs read x: the second data gradient is added to the first
+        a = self.res_m[1](self.res_m[0](self.conv1(xa, res_link=link)), out=buf[:, :half])
+        b = self.conv2(xa, out=buf[:, half:], res_link=link)
         return self.conv3(F_.CatInto.apply(buf, a, b), out=out)
 
 
@@ -126,11 +126,12 @@ class SPPF(nn.Module):
     def forward(self, x):
         c = self.cv1.conv.out_channels
         buf = F_.cat_buffer(x, self.cv1.conv.weight, 4 * c)
-        x, xp = F_.fanout(self.cv1(x, out=buf[:, :c]), 2)                 # each map feeds the concat and the next pool
-        y1, y1p = F_.fanout(F_.MaxPool5.apply(xp, buf[:, c:2 * c]), 2)
-        y2, y2p = F_.fanout(F_.MaxPool5.apply(y1p, buf[:, 2 * c:3 * c]), 2)
-        y3 = F_.MaxPool5.apply(y2p, buf[:, 3 * c:])
-        return self.cv2(F_.CatInto.apply(buf, x, y1, y2, y3))
+        # each map feeds the concat and the next pool: the pool's gradient is added to the concat slice's (F_.fan2)
+        x, l0 = F_.fan2(self.cv1(x, out=buf[:, :c]))
+        y1, l1 = F_.fan2(F_.MaxPool5.apply(x, buf[:, c:2 * c], l0))
+        y2, l2 = F_.fan2(F_.MaxPool5.apply(y1, buf[:, 2 * c:3 * c], l1))
+        y3 = F_.MaxPool5.apply(y2, buf[:, 3 * c:], l2)
+        return self.cv2(F_.CatInto.apply(buf, F_.stash(x, l0), F_.stash(y1, l1), F_.stash(y2, l2), y3))
 
 
 class Attention(nn.Module):

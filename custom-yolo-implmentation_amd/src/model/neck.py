@@ -31,10 +31,11 @@ class Neck(nn.Module):
             first = make_first[0](buf[:, :c1])
             return head(F_.CatInto.apply(buf, first, skip))
 
-        # every tensor with two consumers goes out as two handles (F_.Fanout: its gradients are summed in one pass)
-        p5u, p5s = F_.fanout(p5, 2)
-        p4u, p4s = F_.fanout(joined(self.h1, (lambda o: F_.Upsample2x.apply(p5u, o), p5.shape[1]), p4), 2)
-        p3o, p3d = F_.fanout(joined(self.h2, (lambda o: F_.Upsample2x.apply(p4u, o), p4.shape[1]), p3), 2)
-        p4o, p4d = F_.fanout(joined(self.h4, (lambda o: self.h3(p3d, out=o), self.h3.conv.out_channels), p4s), 2)
-        p5o = joined(self.h6, (lambda o: self.h5(p4d, out=o), self.h5.conv.out_channels), p5s)
-        return p3o, p4o, p5o
+        # every tensor here has two consumers; F_.fan2: the second gradient is added to the first by the kernel that
+        # produces it (upsample backward, stride-2 conv data gradient), autograd never sums
+        p5, l5 = F_.fan2(p5)
+        p4, l4 = F_.fan2(joined(self.h1, (lambda o: F_.Upsample2x.apply(p5, o, l5), p5.shape[1]), p4))
+        p3, l3 = F_.fan2(joined(self.h2, (lambda o: F_.Upsample2x.apply(p4, o, l4), p4.shape[1]), p3))
+        p4b, l4b = F_.fan2(joined(self.h4, (lambda o: self.h3(p3, out=o, res_link=l3), self.h3.conv.out_channels), F_.stash(p4, l4)))
+        p5b = joined(self.h6, (lambda o: self.h5(p4b, out=o, res_link=l4b), self.h5.conv.out_channels), F_.stash(p5, l5))
+        return F_.stash(p3, l3), F_.stash(p4b, l4b), p5b

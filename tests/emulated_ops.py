@@ -150,10 +150,17 @@ def dw_fwd(x, w9):
     return _nhwc(F.conv2d(x.float(), w9.view(c, 1, 3, 3), None, 1, 1, 1, c).to(x.dtype))
 
 
-def dw_dgrad(dy, w9):
+def _acc(acc_into, val, dtype):
+    if acc_into is None:
+        return _nhwc(val.to(dtype))
+    acc_into.data.copy_((acc_into.float() + val).to(acc_into.dtype))
+    return acc_into
+
+
+def dw_dgrad(dy, w9, acc_into=None):
     c = dy.shape[1]
     dx = torch.nn.grad.conv2d_input(tuple(dy.shape), w9.view(c, 1, 3, 3), dy.float(), 1, 1, 1, c)
-    return _nhwc(dx.to(dy.dtype))
+    return _acc(acc_into, dx, dy.dtype)
 
 
 def dw_wgrad(x, dy):
@@ -223,20 +230,20 @@ def maxpool5_fwd(x, out=None):
     return _into(out, _nhwc(o.to(x.dtype))), idx
 
 
-def maxpool5_bwd(dout, idx):
+def maxpool5_bwd(dout, idx, acc_into=None):
     n, c, h, w = dout.shape
     dx = torch.zeros(n, c, h * w)
     dx.scatter_add_(2, idx.reshape(n, c, -1), dout.float().reshape(n, c, -1))
-    return _nhwc(dx.view(n, c, h, w).to(dout.dtype))
+    return _acc(acc_into, dx.view(n, c, h, w), dout.dtype)
 
 
 def upsample2x_fwd(x, out=None):
     return _into(out, _nhwc(F.interpolate(x.float(), scale_factor=2.0, mode="nearest").to(x.dtype)))
 
 
-def upsample2x_bwd(dout):
+def upsample2x_bwd(dout, acc_into=None):
     n, c, oh, ow = dout.shape
-    return _nhwc(dout.float().view(n, c, oh // 2, 2, ow // 2, 2).sum((3, 5)).to(dout.dtype))
+    return _acc(acc_into, dout.float().view(n, c, oh // 2, 2, ow // 2, 2).sum((3, 5)), dout.dtype)
 
 
 def _split_qkv(qkv, heads, dk, dh):

