@@ -67,10 +67,9 @@ def main(args):
         use_wandb = use_wandb and run is not None
 
         model = Model(**model_cfg["config"], num_classes=model_cfg["num_classes"])
-        captured = bool(tr_cfg.get("captured_step", False)) and args.mode == "ddp" and args.device == "cuda" \
-            and args.precision in ("bfloat16", "float32")       # optional key: the step as one replayed hipGraph
-        if captured:
-            tr_cfg[args.mode]["captured_step"] = True
+        # the training step as replayed hipGraphs is the default in ddp mode (optional key `training.captured_step: false`
+        # keeps the reference's eager loop)
+        captured = None if bool(tr_cfg.get("captured_step", True)) else False
         model = WRAP[args.mode](model=model, device_id=gpu, config=tr_cfg[args.mode], world_size=world_size, device=args.device)
         print(f"[INFO] {args.mode.upper()} model initialzed")
         model = model.to(args.device)

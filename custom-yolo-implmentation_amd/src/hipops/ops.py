@@ -119,6 +119,13 @@ def add_n(xs, out=None):
     return out
 
 
+def bucket_copy(plan, scale=1.0):
+    """dst_i = src_i * scale (with dtype cast) for every tensor pair of a GradBuckets plan in ONE launch; `plan` carries
+    the device job table built from the tensors' addresses (plus the tensors themselves, srcs / dsts)."""
+    if plan["njobs"]:
+        lib.call("yolo_multi_copy", _p(plan["dev"]), plan["njobs"], plan["nchunks"], float(scale), _stream(plan["dsts"][0]))
+
+
 def zero_(t):
     lib.call("yolo_memset0", _p(t), t.numel() * t.element_size(), _stream(t))
     return t

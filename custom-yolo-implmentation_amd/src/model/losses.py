@@ -44,14 +44,17 @@ class StaticTargets:
         self._h_img = torch.zeros(capacity, dtype=torch.int32).pin_memory()
         self.n_gt, self._uploaded = 0, None
 
+    def fits(self, gt_boxes_list):
+        """Host-side check only: would load() accept this batch?"""
+        return len(gt_boxes_list) == self.n_img and \
+            sum(int(g.shape[0]) if g.numel() > 0 else 0 for g in gt_boxes_list) <= self.capacity
+
     def load(self, gt_boxes_list):
         """Refill from a batch's list of (Mi, 5) tensors; False (nothing changed) if they do not fit."""
-        if len(gt_boxes_list) != self.n_img:
+        if not self.fits(gt_boxes_list):
             return False
         counts = [int(g.shape[0]) if g.numel() > 0 else 0 for g in gt_boxes_list]
         total = sum(counts)
-        if total > self.capacity:
-            return False
         if self._uploaded is not None:
             self._uploaded.synchronize()                # the previous upload has left the pinned buffers
         off = 0

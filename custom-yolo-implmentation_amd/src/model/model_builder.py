@@ -15,6 +15,10 @@ from src.utils.model_utils import fuse_conv, non_max_suppression
 
 
 class Model(nn.Module):
+    # TrainStepRunner's staged backward: a callable that receives the backbone's outputs and returns what the neck should
+    # read instead (detached leaves), cutting the autograd graph at the backbone / neck boundary
+    stage_cut = None
+
     def __init__(self, width: List[int], depth: List[int], csp: List[bool], num_classes: int):
         super().__init__()
         self.net = Backbone(width, depth, csp)
@@ -31,6 +35,9 @@ class Model(nn.Module):
 
     def forward(self, x):
         if not self.training:
+            # packed weights served by a training pass's plan predate the last optimizer step (a raw kernel updates the
+            # parameters without touching their version counters): evaluation always packs afresh
+            ops.ACTIVE_PACK_PLAN = None
             return self.head(list(self.fpn(self.net(x))))
         convs = [m for m in self.modules() if type(m) is Conv and hasattr(m, "norm")]
         torch._foreach_add_([m.norm.num_batches_tracked for m in convs], 1)
@@ -38,7 +45,10 @@ class Model(nn.Module):
         # one zeroed pool for every layer's BatchNorm accumulators of this pass (a single memset)
         F_.BnArena.current = F_.BnArena(x.device, F_.BnArena.elems_for([m.conv.out_channels for m in convs]))
         try:
-            return self.head(list(self.fpn(self.net(x))))
+            feats = self.net(x)
+            if self.stage_cut is not None:
+                feats = self.stage_cut(feats)
+            return self.head(list(self.fpn(feats)))
         finally:
             F_.BnArena.current = None
 

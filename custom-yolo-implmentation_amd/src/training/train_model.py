@@ -51,45 +51,97 @@ def _make_scaler(precision, distributed_mode, device, rank):
 
 
 class CapturedTraining:
-    """Opt-in (`train(..., captured_step=True)`): training batches go through `TrainStepRunner` -- the step captured
-    once as a hipGraph on static image / target buffers that every batch refills (12.9 instead of 18.2 ms per step on
-    preset s, where the eager loop is bound by the host's launch rate).  The first batch is stepped eagerly (it is
-    also the capture's warm-up); a batch that does not fit the captured shape (other size, more boxes than the
-    capacity) falls back to the eager step.  For a model that is NOT wrapped (single process, or a caller that
-    averages gradients itself through the runner): capturing the backward of a DistributedDataParallel-wrapped module
-    crashes on this stack (the reducer's autograd hooks), so a wrapped model keeps the eager loop.  Needs a capturable
-    optimizer and no GradScaler (bf16 / fp32)."""
+    """Training batches go through `TrainStepRunner`: the step captured once as hipGraphs on static image / target buffers
+    that every batch refills (12.5 instead of 18 ms per step on preset s, where the eager loop is bound by the host's
+    launch rate).  The default in ddp mode on the GPU (`train(captured_step=None)`); `captured_step=False` or the config key
+    `training.captured_step: false` keeps the reference's eager loop.
+
+    A DistributedDataParallel-wrapped model is stepped through its `.module`: the runner averages the gradients itself
+    (two flat buckets, all-reduced beside the backbone's backward: src/training/graph_step.py) -- same mean-over-ranks
+    result as the wrapper's reducer, whose hooks stay idle because the wrapper's own forward is not called.  (Capturing
+    the WRAPPER's forward also works once its logger has stopped sampling, i.e. after 11 eager iterations --
+    tools/capture_probe.py, profiles/r2_capture_probe.log -- but then RCCL kernels sit inside the graph; the eager
+    collectives between graphs are the conservative choice.)  DDP re-broadcasts the BatchNorm buffers from rank 0 before
+    every forward; in training mode nothing reads them, so `sync_buffers()` at the end of the training epoch gives every
+    rank the same running statistics DDP would have left (rank 0's).
+
+    The first fitting batch is stepped eagerly (the capture's warm-up).  Whether a batch fits the captured buffers
+    (batch size, resolution, box capacity) is decided COLLECTIVELY (all-reduce MIN of a host flag over a gloo side
+    group): all ranks replay or all ranks step eagerly, with the same buckets and reduction either way.  Needs a
+    capturable optimizer and no GradScaler (bf16 / fp32)."""
 
     def __init__(self, model, criterion, optimizer, precision):
+        import torch.distributed as dist
         from torch.nn.parallel import DistributedDataParallel as DDP
-        self.inner = model
+        self.wrapper = model
+        self.inner = model.module if isinstance(model, DDP) else model
         self.criterion, self.optimizer, self.precision = criterion, optimizer, precision
-        self.runner, self.dirty = None, False
-        self.usable = not isinstance(model, DDP) and precision in ("bfloat16", "float32") and \
+        self.runner, self.dirty, self.captured = None, False, False
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.flag_group = None
+        self.usable = precision in ("bfloat16", "float32") and \
             all(g.get("capturable", False) for g in optimizer.param_groups) and \
             all(type(p) is torch.nn.Parameter and p.is_cuda for p in self.inner.parameters())
 
+    def _all_fit(self, fits):
+        """AND of the ranks' `fits` flags (host side: no device sync)."""
+        if self.world == 1:
+            return fits
+        import torch.distributed as dist
+        if self.flag_group is None:         # first call, same point of the loop on every rank: a CPU side group
+            self.flag_group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+        t = torch.tensor([1 if fits else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.flag_group)
+        return bool(t.item())
+
     def step(self, images, boxes):
-        """-> LazyLossDict of the step, or None (run this batch eagerly)."""
-        from src.model.losses import LazyLossDict
+        """-> LazyLossDict of the step, or None (run this batch in the caller's eager loop: unusable configuration)."""
+        from src.model.losses import LazyLossDict, StaticTargets
         from src.training.graph_step import TrainStepRunner
         if not self.usable:
             return None
         if self.runner is None:
-            self.runner = TrainStepRunner(self.inner, self.criterion, self.optimizer, self.precision, use_graph=True)
-            self.runner.capture_for_batches(images, boxes, warmup=1)     # one eager step on this batch, then the capture
-            return LazyLossDict(self.runner.warm_scalars)
-        if self.dirty:          # an eager fallback step made the optimizer rebuild the table the captured launch reads
-            restore = getattr(self.optimizer, "restore_capture", None)
-            if restore is not None:
-                restore()
-            self.dirty = False
-        if self.runner.step_batch(images, boxes) is None:
-            # does not fit the captured buffers: the runner's eager step (it averages gradients across ranks too)
-            self.dirty = True
+            self.runner = TrainStepRunner(self.inner, self.criterion, self.optimizer, self.precision, use_graph=True,
+                                          grad_comm_dtype=torch.bfloat16 if self.precision == "bfloat16" else None)
+        if not self.captured:
+            cap = 128 * len(boxes)
+            fits = sum(int(b.shape[0]) if b.numel() else 0 for b in boxes) <= cap
+            if self._all_fit(fits):
+                self.runner.capture_for_batches(images, boxes, warmup=1)    # one eager step on this batch, then the capture
+                self.captured = True
+                return LazyLossDict(self.runner.warm_scalars)
             _, ld = self.runner._eager_step(images, [b.to(images.device) for b in boxes])
             return ld
-        return LazyLossDict(self.runner.scalars)
+        if self._all_fit(self.runner.fits(images, boxes)):
+            if self.dirty:      # an eager fallback step made optimizer / buckets rebuild the tables the captured launches read
+                for obj in (self.optimizer, self.runner.buckets):
+                    restore = getattr(obj, "restore_capture", None)
+                    if restore is not None:
+                        restore()
+                self.dirty = False
+            self.runner.step_batch(images, boxes)
+            return LazyLossDict(self.runner.scalars)
+        # some rank's batch does not fit the captured buffers: every rank takes the runner's eager step
+        self.dirty = True
+        _, ld = self.runner._eager_step(images, [b.to(images.device) for b in boxes])
+        return ld
+
+    def sync_buffers(self):
+        """DistributedDataParallel(broadcast_buffers=True) semantics for the BatchNorm buffers: rank 0's values on every
+        rank (one flat broadcast per dtype) -- call before evaluating or checkpointing."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        by_dtype = {}
+        for b in self.inner.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, 0)
+            off = 0
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
 
 
 def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimizer=None, scaler=None, metrics=None,
@@ -138,11 +190,15 @@ def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimi
 def train(model, train_loader, val_loader, optimizer, scheduler, criterion, initial_epoch, num_epochs, device,
           num_classes=171, rank=0, use_wandb=False, wandb_instance=None, log_interval=10,
           checkpoint_dir="experiments/checkpoints", iou_threshold=0.5, conf_threshold=0.25, distributed_mode="ddp",
-          precision="float32", captured_step=False):
+          precision="float32", captured_step=None):
+    """`captured_step`: None (default) = the captured step wherever it applies (ddp mode on the GPU, bf16 / fp32, plain
+    parameters, capturable optimizer), False = the reference's eager loop, True = as None."""
     use_amp = precision in ("float16", "bfloat16")
     scaler = _make_scaler(precision, distributed_mode, device, rank) if use_amp else None
     captured = CapturedTraining(model, criterion, optimizer, precision) \
-        if (captured_step and device != "cpu" and distributed_mode == "ddp" and scaler is None) else None
+        if (captured_step is not False and device != "cpu" and distributed_mode == "ddp" and scaler is None) else None
+    if captured is not None and not captured.usable:
+        captured = None
     autocast_kw = dict(device_type="cpu" if device == "cpu" else "cuda",
                        dtype=torch.bfloat16 if precision == "bfloat16" else torch.float16,
                        enabled=(distributed_mode == "ddp" and use_amp))       # FSDP modes rely on their MP policy
@@ -163,6 +219,8 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, init
                         captured=captured)
         if rank != -1:
             tr = reduce_values(tr, average=True)
+        if captured is not None:
+            captured.sync_buffers()         # what DDP's per-forward buffer broadcast leaves: rank 0's running statistics
 
         model.eval()
         metrics.reset()

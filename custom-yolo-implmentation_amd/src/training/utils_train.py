@@ -29,7 +29,9 @@ def get_optimizer(model: nn.Module, lr: float, weight_decay: float, patience: in
     whose default eager form issues several small kernels per parameter); sharded parameters (FSDP flat parameters,
     FSDP2 DTensors) keep torch.optim.AdamW."""
     params = list(model.parameters())
-    plain = params and all(type(p) is nn.Parameter and p.is_cuda for p in params)
+    # FSDP1 (use_orig_params=True) exposes plain-looking nn.Parameters that are views of its flat shards, re-pointed
+    # every step: sharded models keep torch.optim.AdamW
+    plain = params and not _is_sharded(model) and all(type(p) is nn.Parameter and p.is_cuda for p in params)
     if plain:
         from src.training.fused_adamw import HipAdamW
         opt = HipAdamW(params, lr=lr, weight_decay=weight_decay)
@@ -110,19 +112,12 @@ def _pin_device(device: str, device_id: int, world_size: int):
 
 def prepare_ddp_model(model: nn.Module, device_id: int, config: Dict[str, Union[str, int]], world_size: int,
                       device: str) -> nn.Module:
-    """DistributedDataParallel: bucketed gradient all-reduce overlapped with backward (reference :167-192).
-    `config["captured_step"]` (opt-in, CUDA only): the model is returned UNWRAPPED after the wrapper's one-time work --
-    parameters and buffers broadcast from rank 0 -- because `train(..., captured_step=True)` then steps it through
-    `TrainStepRunner`, which averages the gradients itself with one flat all-reduce per step (same mean-over-ranks
-    semantics); the backward of a wrapped module cannot be captured on this stack."""
+    """DistributedDataParallel: bucketed gradient all-reduce overlapped with backward (reference :167-192).  `train()`
+    steps the wrapped model through `TrainStepRunner` on its `.module` by default (src/training/train_model.py
+    CapturedTraining): the wrapper keeps its one-time work (parameters and buffers broadcast from rank 0), its
+    state-dict naming and its eager semantics for everything outside the captured step."""
     _pin_device(device, device_id, world_size)
     model = model.to(device_id if device == "cuda" else device)
-    if config and config.get("captured_step") and device == "cuda":
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t.data, 0)
-        return model
     unused = bool(config.get("find_unused_parameters", False)) if config else False
     return DDP(model, device_ids=[device_id] if device == "cuda" else None, find_unused_parameters=unused)
 

@@ -65,6 +65,13 @@ int yolo_adamw_job_bytes();
 int yolo_adamw_job_fill(void* jobs_host, int index, void* p, int p_dtype, const void* g, int g_dtype, float* m, float* v, long n);
 long yolo_adamw_jobs_finalize(void* jobs_host, int njobs);
 int yolo_adamw_step(const void* jobs_dev, int njobs, long nchunks, const double* hyper, float* step, const float* grad_scale, const float* found_inf, hipStream_t st);
+/* ---- gradient exchange: pack / unpack every parameter gradient into / out of the flat communication buffers in one launch
+   (DistributedDataParallel's bucket copies: src/training/utils_train.py:190); jobs: device copy of a host table of
+   yolo_copy_job_bytes() records, dst = src * scale with a dtype cast */
+int yolo_copy_job_bytes();
+int yolo_copy_job_fill(void* jobs_host, int index, const void* src, int src_dtype, void* dst, int dst_dtype, long n);
+long yolo_copy_jobs_finalize(void* jobs_host, int njobs);
+int yolo_multi_copy(const void* jobs_dev, int njobs, long nchunks, float scale, hipStream_t st);
 int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
 long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo);

@@ -51,6 +51,11 @@ def add_n(xs, out=None):
     return _into(out, _nhwc(acc.to(xs[0].dtype)))
 
 
+def bucket_copy(plan, scale=1.0):
+    for s_, d_ in zip(plan["srcs"], plan["dsts"]):
+        d_.copy_((s_.float() * scale).to(d_.dtype))
+
+
 def zero_(t):
     return t.zero_()
 
@@ -342,7 +347,7 @@ def val_match(rows, count, gt, gt_off, iou_threshold, nc, skip_empty_gt, counter
                              + mc.class_gt.tolist(), dtype=torch.int64)
 
 
-LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "add_n", "zero_", "fill_", "pack_weights", "conv_fwd",
+LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "add_n", "bucket_copy", "zero_", "fill_", "pack_weights", "conv_fwd",
           "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad", "bn_stats_acc", "bn_finalize_acc", "bn_act_fwd_train", "bn_act_bwd_train",
           "conv_dgrad", "conv_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "bn_train_stats", "bn_eval_coeffs",
           "bn_act_fwd", "bn_act_bwd", "bn_act_bwd_eval", "channel_sum", "maxpool5_fwd", "maxpool5_bwd",

@@ -72,9 +72,32 @@ def _worker(rank, world, port, out):
     crit(p, gts, a, s)[0].backward()
     g2 = torch.cat([q.grad.flatten() for q in m2.parameters() if q.grad is not None])
 
+    # (4) the same runner with ONE bucket (no stage cut): the bucketing must not change the result
+    m3 = fresh()
+    r3 = TrainStepRunner(m3, crit, torch.optim.SGD(m3.parameters(), lr=0.0), precision="float32", use_graph=False, buckets=1)
+    r3.capture(img, PackedTargets(gts, "cpu"))
+    r3.step()
+    g3 = torch.cat([q.grad.flatten() for q in m3.parameters() if q.grad is not None])
+    assert runner.staged and not r3.staged and len(runner.buckets.flats) == 2 and len(r3.buckets.flats) == 1
+
+    # (5) CapturedTraining's collective decisions: the fit flag is the AND over ranks; sync_buffers leaves rank 0's
+    # BatchNorm buffers everywhere (DistributedDataParallel's broadcast_buffers semantics)
+    from src.training.train_model import CapturedTraining
+    ct = CapturedTraining(m1, crit, opt, "float32")
+    fit_and = [ct._all_fit(True), ct._all_fit(rank == 0), ct._all_fit(False)]
+    with torch.no_grad():
+        for b in m1.buffers():
+            if b.is_floating_point():
+                b.add_(float(rank + 1))
+    ct.sync_buffers()
+    bufs = torch.cat([b.float().flatten() for b in m1.buffers()])
+    all_bufs = [torch.zeros_like(bufs) for _ in range(world)]
+    dist.all_gather(all_bufs, bufs)
+
     red = reduce_values([float(rank), 10.0 + rank, 3.0], average=True)
     if rank == 0:
         torch.save(dict(e1=float((g1 - mean).abs().max()), e2=float((g2 - mean).abs().max()), scale=float(mean.abs().max()),
+                        e3=float((g3 - mean).abs().max()), fit_and=fit_and, buf_diff=float((all_bufs[0] - all_bufs[1]).abs().max()),
                         differs=float((local - mean).abs().max()), red=red), out)
     dist.barrier()
     dist.destroy_process_group()
@@ -88,6 +111,9 @@ def test_two_rank_gloo_gradient_averaging(tmp_path):
     assert r["differs"] > 1e-3 * r["scale"]                 # ranks really had different gradients
     assert r["e1"] <= 1e-5 * r["scale"], r                   # runner == mean of local grads
     assert r["e2"] <= 1e-5 * r["scale"], r                   # DDP wrapper == mean of local grads
+    assert r["e3"] <= 1e-5 * r["scale"], r                   # one bucket == two buckets == mean
+    assert r["fit_and"] == [True, False, False]              # a batch that does not fit on ONE rank sends all ranks eager
+    assert r["buf_diff"] == 0.0                              # buffers after sync_buffers: rank 0's on both ranks
     assert r["red"] == [0.5, 10.5, 3.0]
 
 

@@ -32,11 +32,9 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path
     torch.manual_seed(0)
     model = Model(**NANO, num_classes=80)
     wrap = prepare_ddp_model if mode == "ddp" else prepare_fsdp2_model
-    if captured:        # the captured loop is for an unwrapped model (single process): see CapturedTraining
-        model = model.cuda()
-    else:
-        model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False},
-                     world_size=world, device="cuda")
+    # captured=True: the default drop-in path -- the DDP-wrapped model stepped through TrainStepRunner on its .module
+    model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False},
+                 world_size=world, device="cuda")
     tr, va = get_data_loaders("/nonexistent/train", "/nonexistent/val", "", "", batch_size=4, is_test=True, device="cuda",
                               num_classes=80, res=160)
     opt, sched = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
@@ -55,9 +53,10 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path
 
 
 def test_two_graph_data_parallel_step_equals_single_graph_step(pg):
-    """The N > 1 step of TrainStepRunner (graph 1: fwd+bwd+pack gradients, RCCL all-reduce, graph 2: unpack + AdamW)
-    on a one-rank RCCL group must move the weights exactly like the single-graph step; with bf16-compressed
-    gradients it must stay within bf16 rounding of it."""
+    """The N > 1 step of TrainStepRunner (graph A: fwd + backward of head and neck + pack bucket A, RCCL all-reduce beside
+    graph B: backward of the backbone + pack bucket B, second all-reduce, graph C: unpack + AdamW) on a one-rank RCCL
+    group must leave the gradients of the single-graph step, with two buckets or one; with bf16-compressed buckets it
+    must stay within bf16 rounding of them."""
     from src.model.losses import PackedTargets, YoloDFLQFLoss
     from src.model.model_builder import Model
     from src.training.graph_step import TrainStepRunner
@@ -66,7 +65,7 @@ def test_two_graph_data_parallel_step_equals_single_graph_step(pg):
     gts = [torch.cat([torch.rand(3, 2, generator=g) * 160, torch.rand(3, 2, generator=g) * 60 + 8,
                       torch.randint(0, 80, (3, 1), generator=g).float()], 1).cuda() for _ in range(2)]
 
-    def run(force, comm_dtype):
+    def run(force, comm_dtype, buckets=2):
         torch.manual_seed(0)
         model = Model(**NANO, num_classes=80).cuda().train()
         # lr 0: the weights stay put, so the gradients of the last step are comparable across runs (an Adam update is
@@ -74,22 +73,25 @@ def test_two_graph_data_parallel_step_equals_single_graph_step(pg):
         opt = torch.optim.AdamW(model.parameters(), lr=0.0, weight_decay=0.0, capturable=True, fused=True)
         # fp32 compute: the only run-to-run noise left is the last bits of the atomically summed batch statistics
         r = TrainStepRunner(model, YoloDFLQFLoss(num_classes=80), opt, "float32", use_graph=True,
-                            grad_comm_dtype=comm_dtype, force_comm=force)
+                            grad_comm_dtype=comm_dtype, force_comm=force, buckets=buckets)
         r.capture(img, PackedTargets(gts, img.device), warmup=1)
         for _ in range(2):
             r.step()
         torch.cuda.synchronize()
-        assert (r.graph2 is not None) == force
+        assert (r.graph2 is not None) == force and (r.graph_b is not None) == (force and buckets == 2)
         st = opt.state[next(iter(model.parameters()))]
         assert int(st["step"]) >= 2                                     # the optimizer really stepped (in graph 2)
         return [p.grad.detach().float().clone() for p in model.parameters() if p.grad is not None]
 
-    base, same, comp = run(False, None), run(True, None), run(True, torch.bfloat16)
+    # one graph (no exchange) / staged backward with two buckets all-reduced beside the backbone's backward / one flat
+    # bucket / two bf16-compressed buckets
+    base, same, flat1, comp = run(False, None), run(True, None), run(True, None, buckets=1), run(True, torch.bfloat16)
     gmax = max(float(a.abs().max()) for a in base)
-    for a, b, c in zip(base, same, comp):
+    for a, b, f, c in zip(base, same, flat1, comp):
         scale = a.abs().max().clamp_min(1e-3 * gmax)       # some gradients are mathematically zero (noise only)
-        assert torch.isfinite(b).all() and torch.isfinite(c).all()
-        assert (a - b).abs().max() / scale < 1e-3, "pack / all-reduce / unpack changed the gradients"
+        assert torch.isfinite(b).all() and torch.isfinite(c).all() and torch.isfinite(f).all()
+        assert (a - b).abs().max() / scale < 1e-3, "staged backward / pack / all-reduce / unpack changed the gradients"
+        assert (a - f).abs().max() / scale < 1e-3, "single-bucket exchange changed the gradients"
         assert (a - c).abs().max() / scale < 1e-2, "bf16-compressed exchange outside bf16 rounding"
     assert any(not torch.equal(a, c) for a, c in zip(base, comp))
 
@@ -299,3 +301,157 @@ def test_graph_replays_reproduce_the_eager_forward():
         torch.cuda.synchronize()
         err = float((out.float() - ref).abs().max() / ref.abs().max())
         assert err < 1e-4, f"replay {i}: {err}"
+
+
+def test_capture_survives_pinned_memory_owners_dropped_with_the_collector_enabled(pg):
+    """Regression for the run-order dependent abort of round 1 (commit 3e4e500): objects that own pinned host memory --
+    an optimizer's job table, the StaticTargets of an earlier runner, gradient-bucket tables -- dropped in reference
+    cycles right before a capture, with the garbage collector ENABLED and primed to run.  TrainStepRunner.capture
+    collects before the capture and keeps the collector off until all graphs are captured."""
+    import gc
+    from src.model.losses import PackedTargets, StaticTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.fused_adamw import HipAdamW
+    from src.training.graph_step import TrainStepRunner
+    g = torch.Generator().manual_seed(31)
+    img = torch.randn(2, 3, 160, 160, generator=g).cuda()
+    gts = [torch.cat([torch.rand(3, 2, generator=g) * 160, torch.rand(3, 2, generator=g) * 60 + 8,
+                      torch.randint(0, 80, (3, 1), generator=g).float()], 1).cuda() for _ in range(2)]
+    torch.manual_seed(0)
+    model = Model(**NANO, num_classes=80).cuda().train()
+    crit = YoloDFLQFLoss(num_classes=80)
+    assert gc.isenabled()
+
+    class Cycle:                                   # only the collector can free what hangs off a reference cycle
+        def __init__(self, *owned):
+            self.owned, self.me = owned, self
+    # an earlier runner with its optimizer, static targets and bucket tables: stepped, then dropped in cycles
+    old_opt = HipAdamW(model.parameters(), lr=1e-5)
+    old = TrainStepRunner(model, crit, old_opt, "float32", use_graph=True, force_comm=True)
+    old.capture_for_batches(img, [t.cpu() for t in gts], boxes_per_image=8, warmup=1)
+    old.step()
+    torch.cuda.synchronize()
+    Cycle(old, old_opt, StaticTargets(2, 64, img.device))
+    del old, old_opt
+    gc.set_threshold(1, 1, 1)                      # the collector now runs at (almost) every allocation
+    try:
+        opt = HipAdamW(model.parameters(), lr=1e-5)
+        r = TrainStepRunner(model, crit, opt, "float32", use_graph=True, force_comm=True)
+        r.capture(img, PackedTargets(gts, img.device), warmup=1)
+        for _ in range(2):
+            loss = r.step()
+        torch.cuda.synchronize()
+    finally:
+        gc.set_threshold(700, 10, 10)
+    assert gc.isenabled() and torch.isfinite(loss)
+
+
+def test_eval_after_captured_steps_uses_the_updated_weights():
+    """The one-launch weight packing serves packed copies keyed by the parameter's version counter, which the raw AdamW
+    kernel does not bump: an evaluation pass in the same process must not read the copies packed BEFORE the last
+    optimizer step.  Captured steps, then model.eval(): its output must equal that of a fresh model loaded from the
+    state dict."""
+    from src.model.losses import PackedTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.fused_adamw import HipAdamW
+    from src.training.graph_step import TrainStepRunner
+    g = torch.Generator().manual_seed(41)
+    img = torch.randn(2, 3, 160, 160, generator=g).cuda()
+    gts = [torch.cat([torch.rand(3, 2, generator=g) * 160, torch.rand(3, 2, generator=g) * 60 + 8,
+                      torch.randint(0, 80, (3, 1), generator=g).float()], 1).cuda() for _ in range(2)]
+    torch.manual_seed(0)
+    model = Model(**NANO, num_classes=80).cuda().train()
+    opt = HipAdamW(model.parameters(), lr=3e-3)                  # large steps: stale weights would show
+    r = TrainStepRunner(model, YoloDFLQFLoss(num_classes=80), opt, "bfloat16", use_graph=True)
+    r.capture(img, PackedTargets(gts, img.device), warmup=1)
+    for _ in range(3):
+        r.step()
+    torch.cuda.synchronize()
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        got = model(img)[0].float()
+    twin = Model(**NANO, num_classes=80).cuda()
+    twin.load_state_dict(model.state_dict())
+    twin.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        want = twin(img)[0].float()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def _ddp_rank(rank, world, port, out):
+    """One of two ranks sharing the GPU over gloo: train() on a DDP-wrapped model through the captured default path, rank 1
+    gets one batch with more boxes than the captured capacity (-> every rank must step that batch eagerly)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, ".."), os.path.join(here, "..", "custom-yolo-implmentation_amd")):
+        sys.path.insert(0, os.path.abspath(p))
+    import tempfile
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    from src.model.losses import YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training import train_model as tm
+    from src.training.utils_train import get_optimizer, prepare_ddp_model
+    torch.manual_seed(100 + rank)                       # different initial weights: the wrapper's broadcast equalises them
+    model = prepare_ddp_model(model=Model(**NANO, num_classes=80), device_id=0, config={"precision": "bfloat16"},
+                              world_size=world, device="cuda")
+    assert type(model).__name__ == "DistributedDataParallel"
+
+    class Loader(list):
+        sampler = None
+
+    def batches(n, seed, big_at=None):
+        g = torch.Generator().manual_seed(seed)
+        out_ = Loader()
+        for i in range(n):
+            cnt = [300, 300] if i == big_at else [3 + (i % 3), 1 + rank]
+            img = torch.randn(2, 3, 160, 160, generator=g)
+            tg = [{"boxes": torch.cat([torch.rand(c, 2, generator=g) * 160, torch.rand(c, 2, generator=g) * 60 + 8,
+                                       torch.randint(0, 80, (c, 1), generator=g).float()], 1)} for c in cnt]
+            out_.append((img, tg))
+        return out_
+    tr = batches(6, 7 + rank, big_at=3 if rank == 1 else None)      # 600 boxes > 128 * 2 on rank 1 only
+    va = batches(2, 50 + rank)
+    opt, sched = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
+    seen = []
+    orig = tm.CapturedTraining.step
+
+    def spy(self, images, boxes):
+        ld = orig(self, images, boxes)
+        seen.append((self.captured, self.dirty))
+        return ld
+    tm.CapturedTraining.step = spy
+    with tempfile.TemporaryDirectory() as d:
+        tm.train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched, criterion=YoloDFLQFLoss(num_classes=80),
+                 initial_epoch=0, num_epochs=1, device=0, num_classes=80, rank=rank, checkpoint_dir=d, distributed_mode="ddp",
+                 precision="bfloat16", conf_threshold=0.01)
+    flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()]).cpu()
+    bufs = torch.cat([b.detach().float().reshape(-1) for b in model.buffers()]).cpu()
+    both_w = [torch.zeros_like(flat) for _ in range(world)]
+    both_b = [torch.zeros_like(bufs) for _ in range(world)]
+    dist.all_gather(both_w, flat)
+    dist.all_gather(both_b, bufs)
+    if rank == 0:
+        torch.save(dict(wdiff=float((both_w[0] - both_w[1]).abs().max()), bdiff=float((both_b[0] - both_b[1]).abs().max()),
+                        finite=bool(torch.isfinite(flat).all()), seen=seen), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_captured_ddp_two_ranks_sharing_the_gpu_over_gloo(tmp_path):
+    """The drop-in default on N = 2 (as far as a one-GPU box can go: two processes on the card, gloo instead of RCCL):
+    weights and BatchNorm buffers identical across ranks after an epoch in which rank 1 alone had a batch that does not
+    fit the captured buffers (all ranks must fall back to the eager step for it, with the same buckets / reduction)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "ddp.pt")
+    mp.get_context("spawn")
+    mp.spawn(_ddp_rank, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["finite"] and r["wdiff"] == 0.0 and r["bdiff"] == 0.0, r
+    steps = r["seen"]
+    assert len(steps) == 6 and steps[0][0] and steps[3][1] and not steps[4][1], steps     # captured at 0, eager at 3, replay again at 4
