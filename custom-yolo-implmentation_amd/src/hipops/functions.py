@@ -54,6 +54,24 @@ def side_stream(dev):
     return side
 
 
+_STEP = {}
+
+
+def step_stream(dev):
+    """The one non-default stream per device on which captured training steps are warmed up and captured -- and on which
+    `prepare_ddp_model` constructs DistributedDataParallel: the wrapper keeps every parameter's AccumulateGrad node
+    alive, and autograd runs such a node on the stream it was CREATED on.  Created on the default stream (a plain
+    `DDP(model)`), they drag the default stream into the capture and hipStreamEndCapture dies (tools/capture_probe.py);
+    created on this stream they run where the rest of the captured backward runs."""
+    dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _STEP.get(dev)
+    if st is None:
+        st = _STEP[dev] = torch.cuda.Stream(dev)
+    return st
+
+
 def _issue_wgrads(dev, cur, side):
     """One sync point: join what runs on the side stream, fork, issue every queued piece of work there."""
     if _INFLIGHT.get(dev):

@@ -534,6 +534,51 @@ def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_d
     return out, dpreds, ws
 
 
+def _f32c(t):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("the stand-alone loss helpers take contiguous fp32 tensors")
+    return t
+
+
+def bbox_iou(b1, b2, g=None):
+    """forward (g None) -> iou [M]; backward -> (db1, db2) = g * d iou / d box  (losses.py:9-40 incl. the b1_y2 slip)"""
+    m = b1.shape[0]
+    _f32c(b1), _f32c(b2)
+    if g is None:
+        out = _f32(m, b1.device)
+        lib.call("yolo_bbox_iou", _p(b1), _p(b2), m, _p(out), 0, 0, 0, _stream(b1))
+        return out
+    d1, d2 = torch.empty_like(b1), torch.empty_like(b2)
+    lib.call("yolo_bbox_iou", _p(b1), _p(b2), m, 0, _p(_f32c(g)), _p(d1), _p(d2), _stream(b1))
+    return d1, d2
+
+
+def qfl(pred, target, beta, g=None):
+    """quality_focal_loss (losses.py:46-57): forward -> 0-d loss; backward (g: 0-d device tensor) -> (dpred, dtarget)"""
+    m, c = pred.shape
+    _f32c(pred), _f32c(target)
+    if g is None:
+        out = _f32(1, pred.device)
+        lib.call("yolo_quality_focal_loss", _p(pred), _p(target), m, c, float(beta), _p(out), 0, 0, 0, _stream(pred))
+        return out.reshape(())
+    dp, dtg = torch.empty_like(pred), torch.empty_like(target)
+    lib.call("yolo_quality_focal_loss", _p(pred), _p(target), m, c, float(beta), 0, _p(_f32c(g)), _p(dp), _p(dtg), _stream(pred))
+    return dp, dtg
+
+
+def dfl_loss(pred_dist, target_val, g=None):
+    """distribution_focal_loss (losses.py:63-78): forward -> 0-d loss; backward -> (dpred, dtarget)"""
+    m, c = pred_dist.shape
+    _f32c(pred_dist), _f32c(target_val)
+    if g is None:
+        out = _f32(1, pred_dist.device)
+        lib.call("yolo_distribution_focal_loss", _p(pred_dist), _p(target_val), m, c, _p(out), 0, 0, 0, _stream(pred_dist))
+        return out.reshape(())
+    dp, dtg = torch.empty_like(pred_dist), torch.empty_like(target_val)
+    lib.call("yolo_distribution_focal_loss", _p(pred_dist), _p(target_val), m, c, 0, _p(_f32c(g)), _p(dp), _p(dtg), _stream(pred_dist))
+    return dp, dtg
+
+
 def scale_inplace(x, scale_dev):
     lib.call("yolo_scale_inplace", _p(x), x.numel(), dt(x), _p(scale_dev), _stream(x))
     return x

@@ -10,6 +10,42 @@ import torch.nn as nn
 from src.hipops import functions as F_
 
 
+class _Helper(torch.autograd.Function):
+    """forward / backward of one stand-alone helper: ops leaf `name`(inputs..., extra..., g=None | grad)."""
+
+    @staticmethod
+    def forward(ctx, name, extra, *tensors):
+        from src.hipops import ops
+        ctx.name, ctx.extra = name, extra
+        ts = [t.detach().float().contiguous() for t in tensors]
+        ctx.save_for_backward(*ts)
+        return getattr(ops, name)(*ts, *extra)
+
+    @staticmethod
+    def backward(ctx, g):
+        from src.hipops import ops
+        grads = getattr(ops, ctx.name)(*ctx.saved_tensors, *ctx.extra, g=g.detach().float().contiguous())
+        return (None, None) + tuple(grads)
+
+
+def bbox_iou(box1, box2):
+    """IoU of matching rows of two (M, 4) centre-xywh tensors -> (M,), differentiable.  Reference signature and
+    arithmetic (src/model/losses.py:9-40), including its b1_y2 = h + cy/2 slip and the 1e-6 in the denominator."""
+    return _Helper.apply("bbox_iou", (), box1, box2)
+
+
+def quality_focal_loss(pred_scores, target_scores, beta=2.0):
+    """-(t (1-s)^b log(s+1e-12) + (1-t) s^b log(1-s+1e-12)).sum() / M for (M, C) logits / soft targets
+    (src/model/losses.py:46-57)."""
+    return _Helper.apply("qfl", (float(beta),), pred_scores, target_scores)
+
+
+def distribution_focal_loss(pred_dist, target_val):
+    """Two-bin cross entropy around a continuous target, mean over the M rows of (M, reg_max) logits
+    (src/model/losses.py:63-78)."""
+    return _Helper.apply("dfl_loss", (), pred_dist, target_val)
+
+
 class PackedTargets:
     """GT boxes of a batch flattened for the kernel: gt (G,5) fp32, offsets (N+1) int32, image id (G) int32."""
 

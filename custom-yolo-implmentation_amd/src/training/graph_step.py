@@ -242,7 +242,7 @@ class TrainStepRunner:
         self.static = (images, packed)
         if not self.use_graph:
             return self
-        side = torch.cuda.Stream()
+        side = self.stream = F_.step_stream(images.device)      # warm-up and capture on the stream DDP was built on
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -271,7 +271,7 @@ class TrainStepRunner:
         # thread_local: RCCL's watchdog thread polls events of earlier collectives; in the default (global) mode that
         # query is an error while ANY thread captures
         dev = images.device
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
             self.loss, ld = self._stage_a(images, packed)
             self.scalars = ld._scalars
             if not self.staged:
@@ -284,7 +284,7 @@ class TrainStepRunner:
         self.graph, self.opt_in_graph = g, want_opt
         if self.staged:
             gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=g.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(gb, pool=g.pool(), stream=self.stream, capture_error_mode="thread_local"):
                 self._stage_b(dev)
                 ops.ACTIVE_PACK_PLAN = None
                 self.buckets.pack(1)
@@ -292,7 +292,7 @@ class TrainStepRunner:
         finish = getattr(self.optimizer, "finish_capture", None)     # HipAdamW: upload the job table recorded in capture
         if self.comm and capturable:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(g2, pool=g.pool(), stream=self.stream, capture_error_mode="thread_local"):
                 for s in range(len(self.buckets.stage_params)):
                     self.buckets.unpack(s, self._unpack_scale())
                 self.optimizer.step()

@@ -79,7 +79,9 @@ class CapturedTraining:
         self.runner, self.dirty, self.captured = None, False, False
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.flag_group = None
-        self.usable = precision in ("bfloat16", "float32") and \
+        # a wrapper built elsewhere on the default stream cannot be captured (see prepare_ddp_model): eager loop then
+        self.usable = (not isinstance(model, DDP) or getattr(model, "captured_ok", False)) and \
+            precision in ("bfloat16", "float32") and \
             all(g.get("capturable", False) for g in optimizer.param_groups) and \
             all(type(p) is torch.nn.Parameter and p.is_cuda for p in self.inner.parameters())
 

@@ -119,7 +119,19 @@ def prepare_ddp_model(model: nn.Module, device_id: int, config: Dict[str, Union[
     _pin_device(device, device_id, world_size)
     model = model.to(device_id if device == "cuda" else device)
     unused = bool(config.get("find_unused_parameters", False)) if config else False
-    return DDP(model, device_ids=[device_id] if device == "cuda" else None, find_unused_parameters=unused)
+    if device != "cuda":
+        return DDP(model, device_ids=None, find_unused_parameters=unused)
+    # Built on the step stream: DDP keeps each parameter's AccumulateGrad node alive, and autograd runs such a node on
+    # the stream it was created on -- on the default stream that would pull the default stream into the captured step
+    # (hipStreamEndCapture then dies: tools/capture_probe.py).  `captured_ok` tells CapturedTraining so.
+    from src.hipops import functions as F_
+    st = F_.step_stream(torch.device("cuda", device_id))
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ddp = DDP(model, device_ids=[device_id], find_unused_parameters=unused)
+    torch.cuda.current_stream().wait_stream(st)
+    ddp.captured_ok = True
+    return ddp
 
 
 def prepare_fsdp_model(model: nn.Module, device_id: int, config: Dict[str, Union[str, int]], world_size: int,

@@ -135,6 +135,14 @@ int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* 
 size_t yolo_loss_workspace_bytes(int N, int A, int G);
 int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A, const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl, float lambda_cls, void* dpreds, float* out, void* workspace, hipStream_t st);
 
+/* the reference's module-level loss helpers as stand-alone differentiable fp32 ops (notebook API; the training step uses
+   the fused pass above): bbox_iou (losses.py:9-40, incl. the b1_y2 slip), quality_focal_loss (:46-57),
+   distribution_focal_loss (:63-78).  g == null: forward; g = device gradient (per row for bbox_iou, one scalar for the
+   two losses): backward */
+int yolo_bbox_iou(const float* box1, const float* box2, int M, float* iou, const float* g, float* db1, float* db2, hipStream_t st);
+int yolo_quality_focal_loss(const float* pred, const float* target, int M, int C, float beta, float* out, const float* g, float* dpred, float* dtarget, hipStream_t st);
+int yolo_distribution_focal_loss(const float* pred_dist, const float* target_val, int M, int C, float* out, const float* g, float* dpred, float* dtarget, hipStream_t st);
+
 /* ---- inference decode (model_builder.py:123-136) and class-aware NMS (model_utils.py:174-279, torchvision.ops.nms) */
 int yolo_head_decode(const void* preds, const void* anchors, const void* strides, void* y, int N, int nc, int A, int dtype, hipStream_t st);
 int yolo_dfl_expect(const void* x, void* y, int B, int A, int dtype, hipStream_t st);

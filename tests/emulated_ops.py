@@ -294,6 +294,26 @@ def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_d
     return torch.stack([tot.detach(), dfl.detach(), cls.detach()]).float(), dp, None
 
 
+def _vjp(fn, args, g):
+    leaves = [a.detach().clone().requires_grad_(True) for a in args]
+    with torch.enable_grad():
+        out = fn(*leaves)
+    return torch.autograd.grad(out, leaves, g)
+
+
+def bbox_iou(b1, b2, g=None):
+    return oloss.quirk_iou(b1, b2) if g is None else _vjp(oloss.quirk_iou, (b1, b2), g)
+
+
+def qfl(pred, target, beta, g=None):
+    f = lambda p, t: oloss.qfl_sum(p, t, beta)
+    return f(pred, target) if g is None else _vjp(f, (pred, target), g)
+
+
+def dfl_loss(pred_dist, target_val, g=None):
+    return oloss.dfl_side(pred_dist, target_val) if g is None else _vjp(oloss.dfl_side, (pred_dist, target_val), g)
+
+
 def scale_inplace(x, scale_dev):
     return x.mul_(scale_dev.to(x.dtype))
 
@@ -351,7 +371,7 @@ LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "add_n", "buck
           "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad", "bn_stats_acc", "bn_finalize_acc", "bn_act_fwd_train", "bn_act_bwd_train",
           "conv_dgrad", "conv_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "bn_train_stats", "bn_eval_coeffs",
           "bn_act_fwd", "bn_act_bwd", "bn_act_bwd_eval", "channel_sum", "maxpool5_fwd", "maxpool5_bwd",
-          "upsample2x_fwd", "upsample2x_bwd", "attn_fwd", "attn_bwd", "loss_fwd_bwd", "scale_inplace", "head_decode",
+          "upsample2x_fwd", "upsample2x_bwd", "attn_fwd", "attn_bwd", "loss_fwd_bwd", "bbox_iou", "qfl", "dfl_loss", "scale_inplace", "head_decode",
           "dfl_expect", "nms", "val_select", "val_match"]
 
 

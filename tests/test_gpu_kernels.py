@@ -360,6 +360,41 @@ def test_loss_random_s640_shape(dtype):
     assert err <= lim, err
 
 
+def test_module_level_loss_helpers_match_the_oracle_with_gradients():
+    """bbox_iou / quality_focal_loss / distribution_focal_loss (reference src/model/losses.py:9,46,63) as device ops:
+    values and gradients against the oracle's differentiable restatements (fp32, 1e-5)."""
+    from oracle import loss as ol
+    from src.model.losses import bbox_iou, distribution_focal_loss, quality_focal_loss
+    g = torch.Generator().manual_seed(71)
+    m = 333
+    b1 = torch.cat([torch.rand(m, 2, generator=g) * 100, torch.rand(m, 2, generator=g) * 40 + 5], 1)
+    b2 = b1 + torch.randn(m, 4, generator=g) * 6
+    b2[:, 2:] = b2[:, 2:].abs() + 1
+    b2[:7] = b1[:7] + 500                                   # disjoint boxes: clamp branch
+    w = torch.randn(m, generator=g)
+
+    def both(fn_dev, fn_ref, args, weight=None):
+        dev_args = [a.clone().cuda().requires_grad_(True) for a in args]
+        ref_args = [a.clone().requires_grad_(True) for a in args]
+        od, orf = fn_dev(*dev_args), fn_ref(*ref_args)
+        assert torch.allclose(od.cpu(), orf, rtol=1e-5, atol=1e-6), float((od.cpu() - orf).abs().max())
+        if weight is None:
+            od.backward(), orf.backward()
+        else:
+            od.backward(weight.cuda()), orf.backward(weight)
+        for a, b in zip(dev_args, ref_args):
+            assert torch.allclose(a.grad.cpu(), b.grad, rtol=2e-4, atol=1e-6), float((a.grad.cpu() - b.grad).abs().max())
+
+    both(bbox_iou, ol.quirk_iou, (b1, b2), w)
+    logits = torch.randn(57, 80, generator=g) * 2
+    target = torch.rand(57, 80, generator=g) * (torch.rand(57, 80, generator=g) < 0.05)
+    both(quality_focal_loss, ol.qfl_sum, (logits, target))
+    both(lambda p, t: quality_focal_loss(p, t, beta=1.5), lambda p, t: ol.qfl_sum(p, t, 1.5), (logits, target))
+    dist_logits = torch.randn(91, 16, generator=g)
+    tv = torch.rand(91, generator=g) * 14.98
+    both(distribution_focal_loss, ol.dfl_side, (dist_logits, tv))
+
+
 # ------------------------------------------------------------------------------------------ decode / NMS
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_head_decode_and_dfl(dtype):

