@@ -187,20 +187,30 @@ def test_runner_gradients_equal_plain_autograd(group, precision, monkeypatch):
         torch.cuda.synchronize()
         return grads()
 
+    def rel_l2(want, got):
+        nmax = max(float(a.norm()) for a in want)         # ~0 gradients carry only noise: measured against 1 % of the largest norm
+        return max(float((a - b).norm() / a.norm().clamp_min(1e-2 * nmax)) for a, b in zip(want, got))
+
+    noise = [0.0]
+
     def check(want, got, what):
         gmax = max(float(a.abs().max()) for a in want)
-        nmax = max(float(a.norm()) for a in want)
-        for a, b in zip(want, got):
-            if amp is None:
+        if amp is None:
+            for a, b in zip(want, got):
                 scale = a.abs().max().clamp_min(1e-3 * gmax)
                 assert (a - b).abs().max() / scale < tol, (what, float((a - b).abs().max() / scale))
-            else:
-                # tensors whose gradient is mathematically ~0 carry only noise: measured against 1 % of the largest norm;
-                # a stale or missing gradient (what this test is for) is off by ~100 %
-                rel = float((a - b).norm() / a.norm().clamp_min(1e-2 * nmax))
-                assert rel < 2 * tol, (what, rel)
+        else:
+            # bf16: bounded by the run-to-run noise of plain autograd itself (measured below on this very input: the
+            # batch statistics are summed with float atomics, a last-bit difference flips single bf16 roundings, and this
+            # randomly initialised net with two-image statistics amplifies a perturbation ~150x over its 60 layers --
+            # tools/noise_probe2.py); a stale or missing gradient -- what this test is for -- is off by ~100 %
+            r = rel_l2(want, got)
+            assert r < max(4 * noise[0], 0.15), (what, r, noise[0])
 
     want = plain(img)
+    if amp is not None:
+        noise[0] = max(rel_l2(want, plain(img)) for _ in range(4))
+        print(f"\n[bf16 run-to-run noise of plain autograd, worst tensor rel-L2] {noise[0]:.3e}")
     plain(torch.randn(2, 3, 160, 160, generator=g).cuda())  # freed blocks now hold ANOTHER batch's gradients
     opt = torch.optim.AdamW(model.parameters(), lr=0.0, weight_decay=0.0, capturable=True, fused=True)
     model.zero_grad(set_to_none=True)
