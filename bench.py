@@ -132,6 +132,46 @@ class KernelTimer:
         return groups
 
 
+def measure_preset(preset, batch, res, nc, dev, steps, warmup):
+    """The same captured training step on another preset (extra data point, not the metric)."""
+    from src.model.losses import PackedTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.fused_adamw import HipAdamW
+    from src.training.graph_step import TrainStepRunner
+    torch.manual_seed(0)
+    model = Model(**PRESETS[preset], num_classes=nc).to(dev).train()
+    opt = HipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    img, gts = synthetic_batch(batch, res, nc, 4321, dev)
+    runner = TrainStepRunner(model, YoloDFLQFLoss(num_classes=nc), opt, "bfloat16", use_graph=True)
+    runner.capture(img, PackedTargets(gts, dev))
+    for _ in range(warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = runner.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(images_per_s=round(batch * steps / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), steps=steps, batch=batch,
+                final_loss=round(float(loss), 5))
+
+
+def measure_nms(dev):
+    """Class-aware NMS on BASELINE config 5's tensor (8 x 84 x 33600, fp16) on the device: ms per image."""
+    from oracle.train_step import config5_nms_tensor       # input generator only (shared with the CPU baseline leg)
+    from src.utils.model_utils import non_max_suppression
+    pred = config5_nms_tensor(bs=8).half().to(dev)
+    out = non_max_suppression(pred, conf_thres=0.25, iou_thres=0.45, nc=80)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        out = non_max_suppression(pred, conf_thres=0.25, iou_thres=0.45, nc=80)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    return dict(ms_per_image=round(ms / 8, 3), ms_per_batch=round(ms, 3), images=8,
+                candidates_per_image=int((pred[:, 4:].amax(1) > 0.25).sum()) // 8, kept_per_image=sum(o.shape[0] for o in out) // 8)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +185,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra data points (preset l at 16 images, config-5 NMS)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -238,7 +279,7 @@ def main():
         # measurement of this kernel group is attached with its source, or null when the file is absent
         traffic, traffic_src = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_final_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc.json")))
             if pm.get("kernel") == dom:
                 traffic, traffic_src = pm["hbm_bytes_per_launch"], pm["source"]
         except (OSError, ValueError, KeyError):
@@ -258,11 +299,29 @@ def main():
                             avg_launch_us=round(1e3 * gh["ms"] / gh["launches"], 2),
                             algorithmic_mb_per_launch=round(gh["bytes"] / gh["launches"] / 1e6, 2))
 
+    # ---- extra data points observed by the driver (not the metric): BASELINE config 4's model per GPU and config 5's NMS
+    extra = None
+    hip_graph, opt_in_graph = runner.graph is not None, runner.opt_in_graph
+    if rank == 0 and world == 1 and not args.no_extra and args.preset == "s":
+        del runner, opt, model, packed
+        torch.cuda.empty_cache()
+        extra = {}
+        try:
+            extra["preset_l_640_bf16_16img"] = measure_preset("l", 16, args.res, nc, dev, steps=20, warmup=5)
+            extra["nms_config5_fp16_8img"] = measure_nms(dev)
+        except Exception as e:                     # never lose the headline line to an extra
+            extra["error"] = repr(e)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.train_step import time_cpu_steps
-        cpu = time_cpu_steps("s", args.res, batch=2, steps=8, warmup=1, budget_s=25.0)
+        from oracle.train_step import time_cpu_nms, time_cpu_steps
+        # launched like slurm/distributed_training_cpu.sbatch:87-91: one rank, gloo, DDP gradient averaging, all host threads
+        cpu = time_cpu_steps("s", args.res, batch=2, steps=8, warmup=1, budget_s=22.0)
         cpu["value"] = round(cpu["value"], 3)
+        c1 = time_cpu_steps("n", 320, batch=2, steps=12, warmup=1, budget_s=6.0)        # BASELINE config 1
+        c1["value"] = round(c1["value"], 3)
+        cpu["config1_n320_fp32_batch2"] = c1
+        cpu["nms_config5"] = time_cpu_nms(images=2)
 
     if rank == 0:
         gb = args.batch * world
@@ -271,9 +330,9 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype={"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.precision], data="synthetic",
                    config=dict(workload=f"preset {args.preset} (width {PRESETS[args.preset]['width'][1]}..{PRESETS[args.preset]['width'][5]}, depth {PRESETS[args.preset]['depth'][0]}) {args.res}x{args.res} train step "
                                         f"(fwd+DFL/QFL loss+bwd+grad sync+AdamW), COCO-80 synthetic, {args.batch} img/GPU",
-                               global_batch=gb, parallelism=f"dp{world}", hip_graph=runner.graph is not None,
-                               optimizer_in_graph=runner.opt_in_graph, final_loss=round(final_loss, 5)),
-                   roofline=roofline, roofline_hbm=roofline_hbm, roofline_groups=groups_out, cpu_baseline=cpu)
+                               global_batch=gb, parallelism=f"dp{world}", hip_graph=hip_graph,
+                               optimizer_in_graph=opt_in_graph, final_loss=round(final_loss, 5)),
+                   roofline=roofline, roofline_hbm=roofline_hbm, roofline_groups=groups_out, cpu_baseline=cpu, extra=extra)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                 # rank 0 may still be timing its instrumented step: leave together

@@ -25,8 +25,28 @@ def synthetic_batch(n, res, nc=80, seed=1234, device="cpu"):
     return img.to(device), [t.to(device) for t in gts]
 
 
-def time_cpu_steps(preset="s", res=640, batch=2, steps=6, warmup=1, nc=80, budget_s=25.0):
+def _gloo_world1():
+    """The reference's CPU launch is `torchrun --nproc_per_node=1 ... --device cpu --mode ddp`
+    (slurm/distributed_training_cpu.sbatch:87-91): a gloo process group of one rank (distributed_setup.py:19) whose DDP
+    reducer all-reduces the gradients every step.  Returns (group, owned)."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return (dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")), False
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    return dist.group.WORLD, True
+
+
+def time_cpu_steps(preset="s", res=640, batch=2, steps=6, warmup=1, nc=80, budget_s=25.0, ddp_gloo=True):
+    """fp32 training steps of the oracle restatement launched like the reference's CPU job: one rank, gloo, DDP
+    semantics (the gradients go through one flat all-reduce on the one-rank group), torch's default thread count
+    (src/utils/common.py:25-43: world_size 1 keeps all host threads)."""
+    import torch.distributed as dist
     cfg = ob.PRESETS[preset]
+    group, owned = _gloo_world1() if ddp_gloo else (None, False)
     ps = ParamStore(0, requires_grad=True)
     img, gts = synthetic_batch(batch, res, nc)
     ob.model_forward(ps, img[:1, :, :64, :64], cfg["width"], cfg["depth"], cfg["csp"], nc)      # materialise params
@@ -38,6 +58,14 @@ def time_cpu_steps(preset="s", res=640, batch=2, steps=6, warmup=1, nc=80, budge
         preds, a, s = ob.model_forward(ps, img, cfg["width"], cfg["depth"], cfg["csp"], nc, training=True)
         tot, _, _ = ol.dfl_qfl_loss(preds, gts, a, s, nc)
         tot.backward()
+        if group is not None:                       # DistributedDataParallel's gradient averaging, world size 1
+            flat = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None])
+            dist.all_reduce(flat, group=group)
+            off = 0
+            for p in params:
+                if p.grad is not None:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+                    off += p.numel()
         opt.step()
         return float(tot)
 
@@ -49,6 +77,34 @@ def time_cpu_steps(preset="s", res=640, batch=2, steps=6, warmup=1, nc=80, budge
         step()
         done += 1
     dt = time.perf_counter() - t0
+    if owned:
+        dist.destroy_process_group()
     return dict(value=batch * done / dt, unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{done} fp32 train steps (fwd+loss+bwd+AdamW) of preset '{preset}' @{res}x{res}, batch {batch}, "
-                       f"oracle restatement on {torch.get_num_threads()} host threads, {dt:.1f} s")
+                sample=f"{done} fp32 train steps (fwd+loss+bwd+grad all-reduce on a 1-rank gloo group+AdamW) of preset "
+                       f"'{preset}' @{res}x{res}, batch {batch}, oracle restatement on {torch.get_num_threads()} host threads, {dt:.1f} s")
+
+
+def config5_nms_tensor(bs=8, nc=80, m=33600, seed=0):
+    """BASELINE config 5's NMS / IoU stress tensor: (bs, 4+nc, 33600), boxes random cxcywh on a 1280 canvas,
+    ~15 % of the anchors confident (several thousand candidates per image after conf_thres 0.25, >= 300 kept)."""
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.empty(bs, 4 + nc, m)
+    pred[:, 0:2] = torch.rand(bs, 2, m, generator=g) * 1280
+    pred[:, 2:4] = torch.rand(bs, 2, m, generator=g) * 200 + 20
+    pred[:, 4:] = torch.rand(bs, nc, m, generator=g) * 0.2
+    hot = torch.rand(bs, m, generator=g) < 0.15
+    cls = torch.randint(0, nc, (bs, m), generator=g)
+    val = (torch.rand(bs, 1, m, generator=g) * 0.7 + 0.3) * hot.unsqueeze(1) + 0.1 * (~hot).unsqueeze(1)
+    pred[:, 4:].scatter_(1, cls.unsqueeze(1), val)
+    return pred
+
+
+def time_cpu_nms(images=2):
+    """ms / image of the reference's non_max_suppression path (Python loop + greedy NMS) restated on the host, config-5 tensor."""
+    from . import postproc as opost
+    pred = config5_nms_tensor(bs=images).half().float()
+    t0 = time.perf_counter()
+    out = opost.non_max_suppression(pred.clone(), conf_thres=0.25, iou_thres=0.45, nc=80)
+    dt = time.perf_counter() - t0
+    return dict(value=round(1e3 * dt / images, 1), unit="ms/image", cores=torch.get_num_threads(), kind="port",
+                sample=f"{images} images x 33600 anchors x 80 classes, {sum(o.shape[0] for o in out) // images} kept / image")
