@@ -36,16 +36,30 @@ def _gloo_world1():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    # gloo's transport prints its connection banner to STDOUT; bench.py's stdout carries exactly one JSON line
+    import os
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     return dist.group.WORLD, True
 
 
-def time_cpu_steps(preset="s", res=640, batch=2, steps=6, warmup=1, nc=80, budget_s=25.0, ddp_gloo=True):
+def time_cpu_steps(preset="s", res=640, batch=2, steps=6, warmup=1, nc=80, budget_s=25.0, ddp_gloo=True, threads=None):
     """fp32 training steps of the oracle restatement launched like the reference's CPU job: one rank, gloo, DDP
     semantics (the gradients go through one flat all-reduce on the one-rank group), torch's default thread count
     (src/utils/common.py:25-43: world_size 1 keeps all host threads)."""
     import torch.distributed as dist
     cfg = ob.PRESETS[preset]
+    default_threads = torch.get_num_threads()
+    if threads is not None:
+        torch.set_num_threads(threads)
     group, owned = _gloo_world1() if ddp_gloo else (None, False)
     ps = ParamStore(0, requires_grad=True)
     img, gts = synthetic_batch(batch, res, nc)
@@ -79,9 +93,11 @@ def time_cpu_steps(preset="s", res=640, batch=2, steps=6, warmup=1, nc=80, budge
     dt = time.perf_counter() - t0
     if owned:
         dist.destroy_process_group()
-    return dict(value=batch * done / dt, unit="images/s", cores=torch.get_num_threads(), kind="port",
+    used = torch.get_num_threads()
+    torch.set_num_threads(default_threads)
+    return dict(value=batch * done / max(dt, 1e-9), unit="images/s", cores=used, kind="port",
                 sample=f"{done} fp32 train steps (fwd+loss+bwd+grad all-reduce on a 1-rank gloo group+AdamW) of preset "
-                       f"'{preset}' @{res}x{res}, batch {batch}, oracle restatement on {torch.get_num_threads()} host threads, {dt:.1f} s")
+                       f"'{preset}' @{res}x{res}, batch {batch}, oracle restatement on {used} host threads, {dt:.1f} s")
 
 
 def config5_nms_tensor(bs=8, nc=80, m=33600, seed=0):
