@@ -1,13 +1,30 @@
-"""Data loaders with the reference's entry point (src/data/data_loader.py:11).  The parquet/PIL pipeline
-is outside the accelerated path; when the parquet directory is absent this returns
-loaders over the synthetic COCO-shaped dataset the benchmark uses, in the same (images, [targets]) format."""
+"""Data loaders with the reference's entry point (src/data/data_loader.py:11).  With the parquet files present:
+DataLoader workers decode the images and the reference's transform runs on the device for the whole batch (SURVEY 8f
+row 2, src/data/transforms.py::BatchTransform).  When the parquet directory is absent: loaders over the synthetic
+COCO-shaped dataset the benchmark uses, in the same (images, [targets]) format."""
 import os
 
 import torch
 from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
 
-from src.data.collate import collate_fn
+from src.data.collate import collate_fn, raw_collate_fn
+
+
+class DevicePreppedLoader:
+    """A DataLoader of decoded images whose batches pass through the on-device transform on their way out: yields
+    (images[N,3,S,S] on the device, [targets]) -- the format of src/data/collate.py."""
+
+    def __init__(self, loader, transform):
+        self.loader, self.transform = loader, transform
+        self.sampler, self.dataset, self.batch_size = loader.sampler, loader.dataset, loader.batch_size
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for images, targets in self.loader:
+            yield self.transform(images, targets)
 
 
 class SyntheticDetectionDataset(Dataset):
@@ -31,8 +48,20 @@ class SyntheticDetectionDataset(Dataset):
 def get_data_loaders(train_parquet, val_parquet, train_images, val_images, batch_size, is_test=False, prefetch_factor=2,
                      percent=1.0, device="cpu", num_classes=80, res=640):
     if os.path.exists(train_parquet):
-        raise NotImplementedError("parquet/PIL input pipeline is outside this build's scope (SURVEY 8f); "
-                                  "remove the parquet path to train on the synthetic dataset")
+        # the reference's pipeline (src/data/data_loader.py:11-60): workers decode, the transform runs on the device
+        from src.data.dataset_loader import DetectionDataset
+        from src.data.transforms import get_train_transforms, get_val_transforms
+        from src.utils.common import get_num_workers
+        train_ds = DetectionDataset(train_parquet, train_images, is_test=is_test, percent=percent)
+        val_ds = DetectionDataset(val_parquet, val_images, is_test=is_test, percent=percent)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        ts = DistributedSampler(train_ds, shuffle=True) if dist_on else None
+        vs = DistributedSampler(val_ds, shuffle=False) if dist_on else None
+        nw = 0 if is_test else get_num_workers()
+        kw = dict(num_workers=nw, collate_fn=raw_collate_fn, prefetch_factor=prefetch_factor if nw else None)
+        train = DataLoader(train_ds, batch_size=batch_size, shuffle=ts is None, sampler=ts, drop_last=True, **kw)
+        val = DataLoader(val_ds, batch_size=batch_size, shuffle=False, sampler=vs, **kw)
+        return DevicePreppedLoader(train, get_train_transforms(res, device)), DevicePreppedLoader(val, get_val_transforms(res, device))
     n = 20 if is_test else 256
     train_ds = SyntheticDetectionDataset(max(batch_size, int(n * percent)), res, num_classes, 1234)
     val_ds = SyntheticDetectionDataset(max(batch_size, int(n * percent) // 4), res, num_classes, 4321)

@@ -584,6 +584,26 @@ def scale_inplace(x, scale_dev):
     return x
 
 
+def image_prep(src_u8, recs, size, jitter, dtype, mean, std):
+    """Batch of decoded uint8 HWC images (flat device buffer `src_u8`; recs = [(offset, H, W, flip, order[4], factors[4])])
+    -> normalised (N, 3, size, size) tensor of `dtype`: flip + antialiased bilinear resize + colour jitter + normalise
+    (src/data/transforms.py:4-24) in 2 + 2 x (jitter slots) launches for the whole batch."""
+    n = len(recs)
+    rb = lib.query("yolo_prep_image_bytes")
+    host = torch.zeros(n * rb, dtype=torch.uint8).pin_memory()
+    for i, (off, h, w, flip, order, fac) in enumerate(recs):
+        o = list(order) + [-1] * (4 - len(order))
+        lib.call("yolo_prep_image_fill", host.data_ptr(), i, int(off), int(h), int(w), int(bool(flip)), *[int(v) for v in o],
+                 *[float(v) for v in fac])
+    table = host.to(src_u8.device, non_blocking=True)
+    stage = torch.empty((n, 3, size, size), dtype=torch.uint8, device=src_u8.device)
+    means = torch.empty(4 * n, dtype=torch.float32, device=src_u8.device)
+    out = torch.empty((n, 3, size, size), dtype=dtype, device=src_u8.device)
+    lib.call("yolo_image_prep", _p(src_u8), _p(table), n, size, int(bool(jitter)), _p(stage), _p(means), _p(out), dt(dtype),
+             *[float(v) for v in mean], *[float(v) for v in std], _stream(src_u8))
+    return out
+
+
 def head_decode(preds, anchors, strides, nc):
     n, cp, a = preds.shape
     preds = preds.contiguous()

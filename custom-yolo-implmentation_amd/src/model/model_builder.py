@@ -104,7 +104,7 @@ class Model(nn.Module):
             if not is_pil:
                 raise ValueError("Unsupported image type. Must be path, PIL Image, or Tensor.")
             from src.data.transforms import get_val_transforms
-            image = get_val_transforms()(image)
+            image = get_val_transforms(device=next(self.parameters()).device)([image])[0]      # resize + normalise on the device
         if image.dim() == 3:
             image = image.unsqueeze(0)
         image = image.to(next(self.parameters()).device)

@@ -158,6 +158,13 @@ size_t yolo_val_workspace_bytes(int N, int M, int top_k);
 int yolo_val_select(const void* y, int dtype, int N, int nc, int M, float conf, int top_k, float* out, int* out_count, void* workspace, hipStream_t st);
 int yolo_val_match(const float* pred, const int* count, int N, int top_k, const float* gt, const int* gt_off, double iou_thr, int nc, int skip_empty_gt, long long* counters, int* status, hipStream_t st);
 
+/* ---- on-device input pipeline: the reference's training / validation transform (src/data/transforms.py:4-24:
+   horizontal flip, Resize((S,S)) bilinear + antialias, ColorJitter, ToDtype(scale), Normalize) for a batch of decoded uint8 HWC
+   images of different sizes in one launch sequence; random decisions are drawn on the host (table records) */
+int yolo_prep_image_bytes();
+int yolo_prep_image_fill(void* table_host, int index, long off, int H, int W, int flip, int o0, int o1, int o2, int o3, float brightness, float contrast, float saturation, float hue);
+int yolo_image_prep(const void* src, const void* table_dev, int N, int S, int jitter, void* stage, float* means, void* out, int out_dtype, float m0, float m1, float m2, float s0, float s1, float s2, hipStream_t st);
+
 /* ---- hardware self-tests (instruction semantics the tiled kernels assume; tests/test_gpu_selftest.py; no reference counterpart: model_blocks.py:1) */
 int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st);
 int yolo_selftest_glds(const void* in128x16, void* out64x16, hipStream_t st);

@@ -318,6 +318,15 @@ def scale_inplace(x, scale_dev):
     return x.mul_(scale_dev.to(x.dtype))
 
 
+def image_prep(src_u8, recs, size, jitter, dtype, mean, std):
+    from oracle.image_prep import transform_image
+    outs = []
+    for off, h, w, flip, order, fac in recs:
+        img = src_u8[off:off + h * w * 3].reshape(h, w, 3).numpy()
+        outs.append(transform_image(img, size, flip, tuple(order) if jitter else (), fac, mean, std))
+    return torch.stack(outs).to(dtype)
+
+
 def head_decode(preds, anchors, strides, nc):
     return opost.inference_decode(ParamStore(), preds.float(), anchors.float(), strides.float(), nc).to(preds.dtype)
 
@@ -371,7 +380,7 @@ LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "add_n", "buck
           "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad", "bn_stats_acc", "bn_finalize_acc", "bn_act_fwd_train", "bn_act_bwd_train",
           "conv_dgrad", "conv_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "bn_train_stats", "bn_eval_coeffs",
           "bn_act_fwd", "bn_act_bwd", "bn_act_bwd_eval", "channel_sum", "maxpool5_fwd", "maxpool5_bwd",
-          "upsample2x_fwd", "upsample2x_bwd", "attn_fwd", "attn_bwd", "loss_fwd_bwd", "bbox_iou", "qfl", "dfl_loss", "scale_inplace", "head_decode",
+          "upsample2x_fwd", "upsample2x_bwd", "attn_fwd", "attn_bwd", "loss_fwd_bwd", "image_prep", "bbox_iou", "qfl", "dfl_loss", "scale_inplace", "head_decode",
           "dfl_expect", "nms", "val_select", "val_match"]
 
 
