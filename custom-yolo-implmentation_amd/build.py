@@ -18,7 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
         "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]
 # bit-exact index selection (NMS) and the reference's operation order (loss box decode, cdist form)
-NO_CONTRACT = {"loss.hip", "decode_nms.hip"}
+NO_CONTRACT = {"loss.hip", "decode_nms.hip", "image_prep.hip"}   # + the uint8-level arithmetic of the input pipeline
 
 
 def newest(paths):

@@ -35,6 +35,8 @@ class BatchTransform:
         self.train, self.size, self.device, self.dtype = train, size, torch.device(device), dtype
         self.flip_p, self.jit = flip_p, (brightness, contrast, saturation, hue)
         self.mean, self.std = mean, std
+        self._pinned = None                 # reused pinned upload buffer (one memcpy per image into it, one async H2D per batch)
+        self._uploaded = None
 
     def sample(self):
         """One image's random decisions, drawn like torchvision draws them: (flip, order, factors)."""
@@ -64,9 +66,18 @@ class BatchTransform:
             h, w = int(t.shape[0]), int(t.shape[1])
             recs.append((off, h, w, flip, order, fac))
             off += h * w * 3
-        flat = torch.cat([t.reshape(-1) for t in imgs])
         if self.device.type == "cuda":
-            flat = flat.pin_memory().to(self.device, non_blocking=True)
+            if self._pinned is None or self._pinned.numel() < off:
+                self._pinned = torch.empty(int(off * 1.25), dtype=torch.uint8).pin_memory()
+            elif self._uploaded is not None:
+                self._uploaded.synchronize()        # the previous batch's upload has left the buffer
+            for t, r in zip(imgs, recs):
+                self._pinned[r[0]:r[0] + t.numel()].copy_(t.reshape(-1))
+            flat = self._pinned[:off].to(self.device, non_blocking=True)
+            self._uploaded = torch.cuda.Event()
+            self._uploaded.record(torch.cuda.current_stream(self.device))
+        else:
+            flat = torch.cat([t.reshape(-1) for t in imgs])
         batch = ops.image_prep(flat, recs, self.size, self.train and any(len(p[1]) for p in params), self.dtype, self.mean, self.std)
         out_t = None
         if targets is not None:
