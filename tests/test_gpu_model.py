@@ -236,3 +236,36 @@ def test_all_gradients_within_band_of_fp32_oracle(preset, res, precision):
     bad = [(k, hip[k], cpu[k]) for k in hip if hip[k][1] > 2 * cpu[k][1] + 0.05]
     assert not bad, f"{len(bad)} tensors further from fp32 than twice the CPU bf16 path: {bad[:5]}"
     assert med <= 1.25 * med16 + 0.01, (med, med16)
+
+
+def test_config5_model_half_preset_l_1280_fp16_inference_vs_fp32_oracle():
+    """BASELINE config 5's model half: preset l at 1280 x 1280 in fp16 (eval mode, one image): the raw head output against
+    the fp32 CPU oracle (fp16 band: 2e-2 of the tensor's max), 33600 anchors, and the inference tail (decode + NMS) on
+    that output against the oracle's decode + NMS of the SAME predictions (rows exact up to fp16 rounding of the boxes)."""
+    from oracle import postproc as opost
+    cfg = ob.PRESETS["l"]
+    model = _model(seed=4, cfg=cfg).eval()
+    img = torch.randn(1, 3, 1280, 1280, generator=torch.Generator().manual_seed(21))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        preds, a, s = model(img.cuda())
+    assert preds.shape == (1, 144, 33600) and preds.dtype == torch.float16 and torch.isfinite(preds.float()).all()
+    ps = ParamStore(4)
+    with torch.no_grad():
+        p_ref, a_ref, s_ref = ob.model_forward(ps, img, cfg["width"], cfg["depth"], cfg["csp"], 80, training=False)
+    err = _rel(preds, p_ref)
+    print(f"\n[config 5 model half] l@1280 fp16 eval preds vs fp32 oracle: max-rel {err:.2e}")
+    assert err < 2e-2
+    # the inference tail on this output.  Raw class logits of a freshly initialised head sit at the -4.6 bias (nothing
+    # passes a confidence threshold), so they are shifted to give thousands of candidates, as config 5's stress tensor has
+    from src.hipops import ops
+    from src.utils.model_utils import non_max_suppression
+    shifted = preds.clone()
+    shifted[:, 64:] += 5.0
+    with torch.no_grad():
+        y = ops.head_decode(shifted, a, s, 80)
+        dets = non_max_suppression(y, conf_thres=0.25, iou_thres=0.45, nc=80)
+        y_ref = opost.inference_decode(ParamStore(), shifted.float().cpu(), a.float().cpu(), s.float().cpu(), 80).half()
+        want = opost.non_max_suppression(y_ref.clone(), conf_thres=0.25, iou_thres=0.45, nc=80)
+    assert float((y.float().cpu() - y_ref.float()).abs().max()) <= 2.0 ** -9 * float(y_ref.float().abs().max())   # fp16 decode
+    assert len(dets) == 1 and dets[0].shape == want[0].shape and dets[0].shape[0] == 300
+    assert torch.equal(dets[0][:, 5].cpu().float(), want[0][:, 5].float())          # same classes in the same order

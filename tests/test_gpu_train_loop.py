@@ -21,23 +21,27 @@ def pg():
 
 @pytest.mark.parametrize("mode,precision,captured", [("ddp", "bfloat16", False), ("ddp", "float32", False),
                                                      ("ddp", "float16", False), ("fsdp2", "bfloat16", False),
+                                                     ("fsdp", "bfloat16", False), ("fsdp", "float32", False),
                                                      ("ddp", "bfloat16", True), ("ddp", "float32", True)])
 def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path):
     from src.data.data_loader import get_data_loaders
     from src.model.losses import YoloDFLQFLoss
     from src.model.model_builder import Model
     from src.training.train_model import train
-    from src.training.utils_train import get_optimizer, prepare_ddp_model, prepare_fsdp2_model
+    from src.training.utils_train import get_optimizer, prepare_ddp_model, prepare_fsdp2_model, prepare_fsdp_model
     rank, world, gpu = pg
     torch.manual_seed(0)
     model = Model(**NANO, num_classes=80)
-    wrap = prepare_ddp_model if mode == "ddp" else prepare_fsdp2_model
+    wrap = {"ddp": prepare_ddp_model, "fsdp2": prepare_fsdp2_model, "fsdp": prepare_fsdp_model}[mode]
     # captured=True: the default drop-in path -- the DDP-wrapped model stepped through TrainStepRunner on its .module
-    model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False},
+    model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False,
+                                                      "sharding_strategy": "FULL_SHARD", "auto_wrap_policy_min_params": 20000},
                  world_size=world, device="cuda")
     tr, va = get_data_loaders("/nonexistent/train", "/nonexistent/val", "", "", batch_size=4, is_test=True, device="cuda",
                               num_classes=80, res=160)
     opt, sched = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
+    if mode != "ddp":                       # sharded parameters keep torch.optim.AdamW (FSDP1's are views of its flat shards)
+        assert type(opt) is torch.optim.AdamW
     before = [p.detach().float().clone() for p in model.parameters()][:3]
     train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched,
           criterion=YoloDFLQFLoss(num_classes=80), initial_epoch=0, num_epochs=1, device=gpu, num_classes=80, rank=rank,
