@@ -552,9 +552,17 @@ static dim3 dw_grid(int nrows, int cv) {
     return dim3((unsigned)(nrows < 4096 ? nrows : 4096), (unsigned)ceil_div(cv, tpr));
 }
 
+// dwconv.hip: the strip kernels for 16-bit tensors with 8-channel alignment (-1 = does not qualify)
+int dw_strip_launch(bool flip, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
+                    int accumulate, hipStream_t st);
+int dw_strip_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* partial, int nslab, int N, int H, int W, int C,
+                          int dtype, hipStream_t st);
+
 template <bool FLIP>
 static int dw_launch(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
                      int accumulate, hipStream_t st) {
+    const int fast = dw_strip_launch(FLIP, x, ldx, w, y, ldy, N, H, W, C, dtype, accumulate, st);
+    if (fast >= 0) return fast;
     YOLO_DISPATCH_T(dtype, {
         if (vecok<T>(x, ldx, C) && vecok<T>(y, ldy, C)) {
             constexpr int V = vec_of<T>::N;
@@ -594,7 +602,9 @@ int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float*
     int nrows = N * H;
     int slabs = yolo_dw_wgrad_nslab(N, H);
     int rps = (nrows + slabs - 1) / slabs;
-    YOLO_DISPATCH_T(dtype, {
+    const int fast = dw_strip_wgrad_launch(x, ldx, dy, ldy, partial, slabs, N, H, W, C, dtype, st);
+    if (fast > 0) return fast;
+    if (fast < 0) YOLO_DISPATCH_T(dtype, {
         if (vecok<T>(x, ldx, C) && vecok<T>(dy, ldy, C)) {
             constexpr int V = vec_of<T>::N;
             int cv = C / V, tpr = cv < 256 ? cv : 256;

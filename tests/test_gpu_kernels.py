@@ -183,13 +183,18 @@ def test_stem_fused_conv(dtype, cout, h, w):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("c,h,w", [(16, 12, 12), (24, 7, 9), (128, 10, 10)])
+@pytest.mark.parametrize("c,h,w", [(16, 12, 12), (24, 7, 9), (128, 10, 10), (80, 13, 21), (512, 20, 20), (12, 5, 6), (2056, 3, 5)])
 def test_depthwise(dtype, c, h, w):
+    """odd maps (partial row strips and column blocks), channel groups that do not divide a workgroup (24, 80), more
+    channel groups than a workgroup holds (2056), a channel count without 8-alignment (12: the generic kernel)"""
     o = ops()
-    x, dy = nhwc(rnd(2, c, h, w, seed=20).to(dtype)), nhwc(rnd(2, c, h, w, seed=21).to(dtype), 8)
+    x, dy = nhwc(rnd(2, c, h, w, seed=20).to(dtype)), nhwc(rnd(2, c, h, w, seed=21).to(dtype), 16)   # dy: slice of a wider buffer
     w9 = rnd(c, 9, seed=22, scale=0.3)
     check(o.dw_fwd(dev(x), w9.to(DEV)), emu.dw_fwd(x, w9), dtype, "dw_fwd")
     check(o.dw_dgrad(dev(dy), w9.to(DEV)), emu.dw_dgrad(dy, w9), dtype, "dw_dgrad")
+    prev = nhwc(rnd(2, c, h, w, seed=23).to(dtype))
+    got = o.dw_dgrad(dev(dy), w9.to(DEV), acc_into=dev(prev).clone(memory_format=torch.preserve_format))
+    check(got, (emu.dw_dgrad(dy, w9).float() + prev.float()).to(dtype), dtype, "dw_dgrad accumulate", mult=2.0)
     check(o.dw_wgrad(dev(x), dev(dy)), emu.dw_wgrad(x, dy), torch.float32, "dw_wgrad", mult=4.0)
 
 
