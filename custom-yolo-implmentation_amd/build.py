@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
             if verbose:
                 print(f"[build] compiled {name}", flush=True)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
-    if force or jobs or not os.path.exists(OUT):
+    if force or jobs or not os.path.exists(OUT) or os.path.getmtime(OUT) < newest(objs):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs,
                            capture_output=True, text=True)
         if r.returncode:

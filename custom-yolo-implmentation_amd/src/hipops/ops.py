@@ -153,7 +153,7 @@ class WeightPackPlan:
             njobs += 1 + lib.query("yolo_pack_job_count", s, 1)
         self.dtype, self.njobs = dtype, njobs
         self.total = sum(a + b for a, b in sizes)
-        self.flat = torch.empty(self.total, dtype=dtype, device=dev)
+        self.flat = torch.zeros(self.total, dtype=dtype, device=dev)     # pad columns stay zero: the pack kernel never writes them
         host = torch.zeros(njobs * jb, dtype=torch.uint8)
         self.entries, start, ji = {}, 0, 0
         esz = self.flat.element_size()
