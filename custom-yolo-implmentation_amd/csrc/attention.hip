@@ -287,26 +287,52 @@ template <typename F> int allow_lds(F* fn, size_t bytes) {
 // bf16 / f16 path: the matmuls run on the matrix cores through the batched GEMM (gemm.h); P is
 // materialised ([N*heads][T][Tp], Tp = T rounded up to 32, pad columns zero) and kept for the backward.
 // ------------------------------------------------------------------------------------------------
-// P = softmax(S) row by row; one wave per row
-template <typename T>
+// P = softmax(S) row by row; one wave per row.  Rows of up to 64*RPL columns stay in registers (one read of S, one
+// write of P; the first form read every score three times); longer rows take the looped form (RPL = 0).
+template <typename T, int RPL>
 __global__ void k_softmax_rows(const float* __restrict__ S, T* __restrict__ P, long rows, int Tn, int Tp) {
     const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
     const float* s = S + r * Tp;
-    float mx = -INFINITY;
-    for (int j = lane; j < Tn; j += 64) mx = fmaxf(mx, s[j]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < Tn; j += 64) sum += __expf(s[j] - mx);
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
     T* p = P + r * Tp;
-    for (int j = lane; j < Tp; j += 64) p[j] = from_f<T>(j < Tn ? __expf(s[j] - mx) * inv : 0.f);
+    if constexpr (RPL > 0) {
+        float v[RPL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int j = lane + 64 * i;
+            v[i] = j < Tn ? s[j] : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            v[i] = __expf(v[i] - mx);                       // exp(-inf) = 0 for the columns past Tn
+            sum += v[i];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int j = lane + 64 * i;
+            if (j < Tp) p[j] = from_f<T>(v[i] * inv);
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int j = lane; j < Tn; j += 64) mx = fmaxf(mx, s[j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < Tn; j += 64) sum += __expf(s[j] - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int j = lane; j < Tp; j += 64) p[j] = from_f<T>(j < Tn ? __expf(s[j] - mx) * inv : 0.f);
+    }
 }
 
-// dS = P * (dP - rowsum(P*dP)); one wave per row
-template <typename T>
+// dS = P * (dP - rowsum(P*dP)); one wave per row, same two forms
+template <typename T, int RPL>
 __global__ void k_softmax_bwd_rows(const T* __restrict__ P, const float* __restrict__ dP, T* __restrict__ dS, long rows,
                                    int Tn, int Tp) {
     const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -314,11 +340,29 @@ __global__ void k_softmax_bwd_rows(const T* __restrict__ P, const float* __restr
     const int lane = threadIdx.x & 63;
     const T* p = P + r * Tp;
     const float* g = dP + r * Tp;
-    float d = 0.f;
-    for (int j = lane; j < Tn; j += 64) d += to_f<T>(p[j]) * g[j];
-    d = wave_sum(d);
     T* o = dS + r * Tp;
-    for (int j = lane; j < Tp; j += 64) o[j] = from_f<T>(j < Tn ? to_f<T>(p[j]) * (g[j] - d) : 0.f);
+    if constexpr (RPL > 0) {
+        float pv[RPL], gv[RPL];
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int j = lane + 64 * i;
+            pv[i] = j < Tn ? to_f<T>(p[j]) : 0.f;
+            gv[i] = j < Tn ? g[j] : 0.f;
+            d += pv[i] * gv[i];
+        }
+        d = wave_sum(d);
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int j = lane + 64 * i;
+            if (j < Tp) o[j] = from_f<T>(pv[i] * (gv[i] - d));
+        }
+    } else {
+        float d = 0.f;
+        for (int j = lane; j < Tn; j += 64) d += to_f<T>(p[j]) * g[j];
+        d = wave_sum(d);
+        for (int j = lane; j < Tp; j += 64) o[j] = from_f<T>(j < Tn ? to_f<T>(p[j]) * (g[j] - d) : 0.f);
+    }
 }
 
 // dst[p][h*dgs + doff + d] = src[p][h*sgs + soff + d], d < width (16-byte packets)
@@ -370,7 +414,10 @@ int attn_fwd_mfma(const T* qkv, int ldq, T* o, int ldo, T* vp, int ldv, T* P, fl
     int rc = gemm_batched_launch(g, dtype, st);
     if (rc) return rc;
     const long rows = (long)N * heads * Tn;
-    hipLaunchKernelGGL((k_softmax_rows<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, rows, Tn, Tp);
+    if (Tp <= 448)
+        hipLaunchKernelGGL((k_softmax_rows<T, 7>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, rows, Tn, Tp);
+    else
+        hipLaunchKernelGGL((k_softmax_rows<T, 0>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, rows, Tn, Tp);
     // O = P V
     g.A = operand(P, pb0, pb1, Tp, 1);
     g.B = operand(qkv + 2 * dk, (long)Tn * ldq, cq, ldq, 0);
@@ -397,7 +444,10 @@ int attn_bwd_mfma(const T* qkv, int ldq, const T* d_o, int lddo, const T* d_vp, 
     int rc = gemm_batched_launch(g, dtype, st);
     if (rc) return rc;
     const long rows = (long)N * heads * Tn;
-    hipLaunchKernelGGL((k_softmax_bwd_rows<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, dS, rows, Tn, Tp);
+    if (Tp <= 448)
+        hipLaunchKernelGGL((k_softmax_bwd_rows<T, 7>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, dS, rows, Tn, Tp);
+    else
+        hipLaunchKernelGGL((k_softmax_bwd_rows<T, 0>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, dS, rows, Tn, Tp);
     // dV = P^T dO (+ d_vp, copied into the v slots first)
     if (d_vp) {
         rc = group_copy<T>(d_vp, lddv, dh, 0, dqkv, lddq, cq, 2 * dk, (long)N * Tn, heads, dh, st);

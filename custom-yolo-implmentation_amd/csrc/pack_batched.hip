@@ -55,6 +55,27 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const PackJob* __restrict__ 
     const int on = O - o0 < TB ? O - o0 : TB, in = I - i0 < TB ? I - i0 : TB;
     const int run = in * kk;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wdt == YOLO_F32 && ((I * kk) & 3) == 0 && (run & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        // 16-byte loads, all of a thread's (up to 9) in flight before the first LDS store
+        const int r4 = run >> 2, n4 = on * r4;
+        float4 v[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int e = threadIdx.x + q * 256;
+            if (e < n4) {
+                const int r = e / r4, c = e - r * r4;
+                v[q] = *reinterpret_cast<const float4*>((const float*)w + ((long)(o0 + r) * I + i0) * kk + c * 4);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int e = threadIdx.x + q * 256;
+            if (e < n4) {
+                const int r = e / r4, c = (e - r * r4) * 4;
+                tile[r][c] = v[q].x; tile[r][c + 1] = v[q].y; tile[r][c + 2] = v[q].z; tile[r][c + 3] = v[q].w;
+            }
+        }
+    } else
     for (int r = wave; r < on; r += 4) {
         const long src = ((long)(o0 + r) * I + i0) * kk;
         for (int c = lane; c < run; c += 64)

@@ -186,6 +186,168 @@ __global__ __launch_bounds__(256) void k_stem_conv(const float* __restrict__ img
     }
 }
 
+// ---- weight gradient straight from the NCHW image: dW[co][k] = sum_p dY[p][co] * unfold(img)[p][k] -----------------
+// Same tile as the forward (two output rows x 128 pixels, the 3 x 5 input row segments staged once in LDS) plus the
+// tile's dY rows in their natural [pixel][channel] order.  The reduction index is the pixel: per group of 32 consecutive
+// output pixels the dY^T fragments come out of LDS through the transposing read (as in k_wgrad2) and the unfold
+// fragments are gathered from the staged image rows (8 consecutive pixels of one k = (ci, kh, kw) per lane, rounded
+// to the compute dtype exactly as the column tensor was).  A workgroup walks tiles with a grid stride, keeps
+// [Cout][32] sums per wave in registers, combines its waves in LDS and stores ONE partial matrix;
+// k_stem_wgrad_reduce sums the workgroups straight into the OIHW gradient.  No column tensor exists any more.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+template <typename T>
+__device__ __forceinline__ typename mfma_ops<T>::frag stem_tr_frag(const T* p_lo, const T* p_hi) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_lo);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_hi);
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename mfma_ops<T>::frag, both);
+}
+
+constexpr int stem_ldy(int ct) { return ct == 4 ? 72 : ct == 8 ? 144 : ct * 16 + (ct == 2 ? 0 : 8); }
+
+template <typename T, int CT>
+__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ img, const T* __restrict__ dy, int ldy,
+                                                    float* __restrict__ part, int N, int H, int W, int OH, int OW, long tiles) {
+    typedef mfma_ops<T> ops;
+    typedef typename ops::frag frag;
+    constexpr int LDY = stem_ldy(CT), COUT = 16 * CT;
+    __shared__ __attribute__((aligned(16))) float rows[3 * STEM_IR][STEM_ROWW + 7];
+    __shared__ __attribute__((aligned(16))) T ys[2 * STEM_SEG * LDY];
+    __shared__ float sum[COUT * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
+    const int segs = (OW + STEM_SEG - 1) / STEM_SEG, ohp = (OH + 1) >> 1;
+    f32x4 acc[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this lane's two unfold columns: k = nt*16 + i16 -> (ci, kh, kw); k >= 27 reads nothing
+    int krow[2], kcol[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int k = nt * 16 + i16, ci = k / 9, r3 = k / 3;
+        krow[nt] = k < 27 ? ci * STEM_IR + (r3 - ci * 3) : -1;
+        kcol[nt] = k - r3 * 3 + 3;
+    }
+    for (long tl = blockIdx.x; tl < tiles; tl += gridDim.x) {
+        const int seg = (int)(tl % segs);
+        const long t = tl / segs;
+        const int oh0 = (int)(t % ohp) * 2, n = (int)(t / ohp);
+        const int ow0 = seg * STEM_SEG, iw0 = 2 * ow0 - 1;
+        __syncthreads();                                    // the previous tile's fragments have been read
+        if ((W & 3) == 0) {
+            for (int r = wave; r < 3 * STEM_IR; r += 4) {
+                const int ci = r / STEM_IR, ir = r - ci * STEM_IR;
+                const int ih = 2 * oh0 + ir - 1;
+                const bool rok = ih >= 0 && ih < H;
+                const float* src = img + (((long)n * 3 + ci) * H + (rok ? ih : 0)) * (long)W + 2 * ow0;
+                const int c = lane * 4;
+                float4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rok && 2 * ow0 + c < W) v = *reinterpret_cast<const float4*>(src + c);
+                *reinterpret_cast<float4*>(&rows[r][4 + c]) = v;
+                if (lane == 0) rows[r][3] = (rok && ow0 > 0) ? src[-1] : 0.f;
+            }
+        } else {
+            for (int idx = tid; idx < 3 * STEM_IR * STEM_ROWW; idx += 256) {
+                const int r = idx / STEM_ROWW, c = idx - r * STEM_ROWW;
+                const int ci = r / STEM_IR, ir = r - ci * STEM_IR;
+                const int ih = 2 * oh0 + ir - 1, iw = iw0 + c;
+                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                rows[r][3 + c] = ok ? img[(((long)n * 3 + ci) * H + ih) * (long)W + iw] : 0.f;
+            }
+        }
+        // dY: 2 rows x 128 pixels x COUT channels, 16-byte chunks; pixels past the row / image end are zeros
+        constexpr int CPP = COUT / 8;
+        for (int id = tid; id < 2 * STEM_SEG * CPP; id += 256) {
+            const int px = id / CPP, ch = (id - px * CPP) * 8;
+            const int j = px / STEM_SEG, p = px - j * STEM_SEG;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (oh0 + j < OH && ow0 + p < OW)
+                v = *reinterpret_cast<const uint4*>(dy + (((long)n * OH + oh0 + j) * OW + ow0 + p) * (long)ldy + ch);
+            *reinterpret_cast<uint4*>(ys + px * LDY + ch) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                       // wave w: the 32-pixel group w of both output rows
+            const int px0 = wave * 32;
+            frag fb[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = krow[nt] >= 0 ? rows[krow[nt] < 0 ? 0 : krow[nt] + 2 * j][2 * (px0 + 8 * g + e) + kcol[nt]] : 0.f;
+                    fb[nt][e] = from_f<T>(v);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const T* p = ys + (j * STEM_SEG + px0 + 8 * g + q) * LDY + ct * 16 + c4;
+                const frag fa = stem_tr_frag<T>(p, p + 4 * LDY);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[ct][nt] = ops::mma(fa, fb[nt], acc[ct][nt]);
+            }
+        }
+    }
+    // D rows = co (ct*16 + g*4 + r), cols = k (nt*16 + i16)
+    // the four waves add their sums one after the other (fixed order: the result does not depend on the schedule)
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* e = &sum[(ct * 16 + g * 4 + r) * 32 + nt * 16 + i16];
+                        *e = wv == 0 ? acc[ct][nt][r] : *e + acc[ct][nt][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* o = part + (long)blockIdx.x * COUT * 32;
+    for (int c = tid; c < COUT * 32; c += 256) o[c] = sum[c];
+}
+
+// dw[o][k] (OIHW (Cout,3,3,3) flat, k < 27) = sum over the workgroups' partial matrices; 32 lanes per element
+template <typename P>
+__global__ __launch_bounds__(256) void k_stem_wgrad_reduce(const float* __restrict__ part, int nslab, int Cout, P* __restrict__ dw) {
+    const int e = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (e >= Cout * 27) return;
+    const int o = e / 27, k = e - o * 27;
+    float s = 0.f;
+    for (int b = l; b < nslab; b += 32) s += part[((long)b * Cout + o) * 32 + k];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 32);
+    if (l == 0) dw[e] = from_f<P>(s);
+}
+
+constexpr int STEM_WG_SLABS = 1024;
+
+template <typename T>
+int launch_stem_wgrad(const float* img, const void* dy, int ldy, float* part, int N, int H, int W, int OH, int OW, int Cout,
+                      int* nslab, hipStream_t st) {
+    const long tiles = (long)N * ((OH + 1) / 2) * ((OW + STEM_SEG - 1) / STEM_SEG);
+    if (tiles <= 0) return YOLO_ERR_ARG;
+    const int grid = (int)(tiles < STEM_WG_SLABS ? tiles : STEM_WG_SLABS);
+    *nslab = grid;
+#define STEM_WG(CT) hipLaunchKernelGGL((k_stem_wgrad<T, CT>), dim3(grid), dim3(256), 0, st, img, (const T*)dy, ldy, part, N, H, W, OH, OW, tiles)
+    switch (Cout / 16) {
+        case 1: STEM_WG(1); break;
+        case 2: STEM_WG(2); break;
+        case 3: STEM_WG(3); break;
+        case 4: STEM_WG(4); break;
+        case 6: STEM_WG(6); break;
+        case 8: STEM_WG(8); break;
+        default: return YOLO_ERR_ARG;
+    }
+#undef STEM_WG
+    return YOLO_LAUNCH_CHECK();
+}
+
 template <typename T>
 int launch_stem_conv(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW,
                      int Cout, hipStream_t st) {
@@ -268,6 +430,29 @@ int yolo_stem_conv_fwd(const float* img, const void* wp, void* y, int ldy, float
     if (OH != (H - 1) / 2 + 1 || OW != (W - 1) / 2 + 1) return YOLO_ERR_ARG;
     if (dtype == YOLO_BF16) return launch_stem_conv<bf16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, st);
     return launch_stem_conv<f16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, st);
+}
+
+// number of partial matrices yolo_stem_wgrad may write: partial = fp32 [yolo_stem_wgrad_slabs()][Cout][32] scratch
+int yolo_stem_wgrad_slabs(void) { return STEM_WG_SLABS; }
+
+// dw OIHW (Cout,3,3,3) of dw_dtype = weight gradient of the stem conv from the fp32 NCHW image and dy[N][OH][OW][ldy >= Cout]
+// (dtype bf16/f16; same eligibility as yolo_stem_conv_fwd).  Replaces unfold + 1x1 weight gradient + unpack.
+int yolo_stem_wgrad(const float* img, const void* dy, int ldy, float* partial, void* dw, int dw_dtype, int N, int H, int W,
+                    int OH, int OW, int Cout, int dtype, hipStream_t st) {
+    if (!yolo_stem_conv_eligible(YOLO_F32, dtype, Cout) || ldy < Cout || (ldy & 7) || (reinterpret_cast<uintptr_t>(dy) & 15)) return YOLO_ERR_ARG;
+    if (OH != (H - 1) / 2 + 1 || OW != (W - 1) / 2 + 1) return YOLO_ERR_ARG;
+    int nslab = 0;
+    const int rc = dtype == YOLO_BF16 ? launch_stem_wgrad<bf16_t>(img, dy, ldy, partial, N, H, W, OH, OW, Cout, &nslab, st)
+                                      : launch_stem_wgrad<f16_t>(img, dy, ldy, partial, N, H, W, OH, OW, Cout, &nslab, st);
+    if (rc) return rc;
+    const int grid = (Cout * 27 + 7) / 8;
+    switch (dw_dtype) {
+        case YOLO_F32:  hipLaunchKernelGGL((k_stem_wgrad_reduce<float>), dim3(grid), dim3(256), 0, st, partial, nslab, Cout, (float*)dw); break;
+        case YOLO_BF16: hipLaunchKernelGGL((k_stem_wgrad_reduce<bf16_t>), dim3(grid), dim3(256), 0, st, partial, nslab, Cout, (bf16_t*)dw); break;
+        case YOLO_F16:  hipLaunchKernelGGL((k_stem_wgrad_reduce<f16_t>), dim3(grid), dim3(256), 0, st, partial, nslab, Cout, (f16_t*)dw); break;
+        default: return YOLO_ERR_DTYPE;
+    }
+    return YOLO_LAUNCH_CHECK();
 }
 
 }  // extern "C"

@@ -300,10 +300,9 @@ class ConvBnAct(torch.autograd.Function):
         # stem: a 3-channel image feeding a 3x3/2 conv is unfolded once (from NCHW directly) and then
         # runs as a 1x1 conv over K = 32 columns; x (saved for wgrad) becomes that column tensor
         stem = (not depthwise and weight.shape[1] == 3 and k == 3 and stride == 2 and not ctx.needs_input_grad[0])
-        # Without a weight gradient to compute (inference, frozen stem) the conv reads the NCHW image directly.  In
-        # training the unfolded tensor is needed by the weight gradient anyway; the fused forward plus an unfold in
-        # backward was 0.5 % SLOWER per step (the step is bound by total kernel time, not by the forward chain).
-        stem_fused = stem and x.is_cuda and not ctx.needs_input_grad[1] and ops.stem_conv_eligible(x, T, cout)
+        # On the device the conv reads the fp32 NCHW image directly (no column tensor) and so does its weight gradient
+        # (ops.stem_wgrad); the unfold + 1x1 route remains for dtypes / channel counts the fused kernels do not take.
+        stem_fused = stem and x.is_cuda and ops.stem_conv_eligible(x, T, cout)
         if stem_fused:
             x = x if x.is_contiguous() else x.contiguous()
             y = ops.stem_conv_fwd(x, ops.stem_pack_weights(weight, T), cout, T, acc_f)
@@ -343,6 +342,7 @@ class ConvBnAct(torch.autograd.Function):
         saved = (scale, shift, mean, invstd, g32)
         ctx.acc_b = acc_b       # a slice of the arena other layers write to: kept off save_for_backward's version check
         ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype, stem)
+        ctx.stem_fused = stem_fused
         ctx.save_for_backward(x, weight, y, *saved)
         return _fresh(out)
 
@@ -364,7 +364,9 @@ class ConvBnAct(torch.autograd.Function):
         n, cin, h, w = xshape
         if stem:
             if ctx.needs_input_grad[1]:
-                def stem_dw(out=None):          # x is the unfolded column tensor
+                def stem_dw(out=None):          # x is the fp32 image (fused) or the unfolded column tensor
+                    if ctx.stem_fused:
+                        return ops.stem_wgrad(x, dy, weight.dtype, out)
                     return ops.stem_unpack_wgrad(ops.conv_wgrad(x, dy, 1, 1, torch.float32), weight.dtype, out)
                 if x.is_cuda and LAZY_WGRAD_JOIN:
                     dwb = torch.empty(weight.shape, dtype=weight.dtype, device=x.device)

@@ -329,6 +329,17 @@ def stem_conv_fwd(img, wp, cout, dtype, stats_acc=None):
     return y
 
 
+def stem_wgrad(img, dy, w_dtype, out=None):
+    """Weight gradient (Cout,3,3,3) of the stem conv straight from the fp32 NCHW image and dy (NHWC, bf16/f16)."""
+    n, _, h, w = img.shape
+    _, cout, oh, ow, ldy = geom(dy)
+    dw = torch.empty((cout, 3, 3, 3), dtype=w_dtype, device=img.device) if out is None else out
+    assert dw.shape == (cout, 3, 3, 3) and dw.dtype == w_dtype and dw.is_contiguous() and img.is_contiguous()
+    part = torch.empty(lib.query("yolo_stem_wgrad_slabs") * cout * 32, dtype=torch.float32, device=img.device)
+    lib.call("yolo_stem_wgrad", _p(img), _p(dy), ldy, _p(part), _p(dw), dt(w_dtype), n, h, w, oh, ow, cout, dt(dy), _stream(img))
+    return dw
+
+
 def stem_pack_weights(w, dtype):
     """OIHW (Cout,3,3,3) -> forward-packed [Cout][32] matrix for conv_fwd(k=1) on the column tensor."""
     w = w if w.is_contiguous() else w.contiguous()

@@ -95,6 +95,10 @@ int yolo_stem_unpack_wgrad(const float* dw32, int Cout, void* dw, int dw_dtype, 
 /* fused stem forward: conv straight from the NCHW fp32 image (no column tensor), BatchNorm statistics in the epilogue */
 int yolo_stem_conv_eligible(int img_dtype, int dtype, int Cout);
 int yolo_stem_conv_fwd(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW, int Cout, int dtype, hipStream_t st);
+/* stem weight gradient straight from the image (autograd's conv2d weight gradient of backbone.py:38; no column tensor):
+   partial = fp32 scratch [yolo_stem_wgrad_slabs()][Cout][32]; dw = OIHW (Cout,3,3,3) of dw_dtype */
+int yolo_stem_wgrad_slabs();
+int yolo_stem_wgrad(const float* img, const void* dy, int ldy, float* partial, void* dw, int dw_dtype, int N, int H, int W, int OH, int OW, int Cout, int dtype, hipStream_t st);
 /* depthwise 3x3 (groups == channels: model_blocks.py:183, head.py:56,58) */
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype, hipStream_t st);
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int accumulate, int dtype, hipStream_t st);

@@ -182,6 +182,27 @@ def test_stem_fused_conv(dtype, cout, h, w):
     assert torch.allclose(st, want, rtol=2e-4, atol=1e-3 * float(want.abs().max())), (st - want).abs().max()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cout,h,w,pad", [(16, 32, 32, 0), (32, 17, 23, 16), (64, 640, 322, 0), (48, 9, 515, 0), (96, 6, 6, 16), (128, 34, 258, 0)])
+def test_stem_fused_wgrad(dtype, cout, h, w, pad):
+    """weight gradient straight from the NCHW fp32 image == the unfold + 1x1 weight gradient (same rounded operands, fp32
+    accumulation in another order) and == the fp32 reference of the 3x3/2 conv; odd sizes, partial segments and row pairs,
+    every channel-tile count, dy as a channel slice of a wider buffer"""
+    o = ops()
+    img = rnd(2, 3, h, w, seed=24)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dy = nhwc(rnd(2, cout, oh, ow, seed=25).to(dtype), pad)
+    dw = o.stem_wgrad(img.to(DEV), dev(dy), torch.float32)
+    col = o.stem_im2col(img.to(DEV), dtype)
+    dw_unf = o.stem_unpack_wgrad(o.conv_wgrad(col, dev(dy), 1, 1, torch.float32), torch.float32)
+    scale = float(dw_unf.abs().max())
+    assert float((dw - dw_unf).abs().max()) <= 2e-4 * scale, ((dw - dw_unf).abs().max(), scale)
+    dw_ref = emu.conv_wgrad(nhwc(img.to(dtype)), dy, 3, 2, torch.float32)
+    check(dw, dw_ref, torch.float32, "fused stem wgrad", mult=4.0)
+    dwb = o.stem_wgrad(img.to(DEV), dev(dy), torch.bfloat16)
+    assert dwb.dtype == torch.bfloat16 and torch.equal(dwb.float().cpu(), dw.cpu().to(torch.bfloat16).float())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("c,h,w", [(16, 12, 12), (24, 7, 9), (128, 10, 10), (80, 13, 21), (512, 20, 20), (12, 5, 6), (2056, 3, 5)])
 def test_depthwise(dtype, c, h, w):
