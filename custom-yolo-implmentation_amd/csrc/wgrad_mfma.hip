@@ -39,7 +39,16 @@ struct WgArgs {
     int N, H, W, Cin, ldx, OH, OW, Cout, ldy, Kpad;
     int pbh, pbw;            // patches per image along h / w
     long npatch, per_slab;
+    int cot, cit;            // (co, ci) tiles
+    int xcd;                 // 1: XCD-aware order of the work items
 };
+
+// bijective XCD-aware remap (workgroup i runs on XCD i % 8): workgroups that share an XCD get a contiguous range of
+// work items, so the tiles of one slab -- which read the same X / dY rows -- sit behind one L2
+__device__ __forceinline__ int xcd_chunk(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 
 // two transposing reads -> one MFMA fragment: element j = LDS[(row0 + (j&3) + 4*(j>>2)*rstep ... )]
 template <typename T>
@@ -67,8 +76,10 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wi = wave & 1;
     // block tile = (2 waves x TCO x 16) co  x  (2 waves x TCI x 16) ci
-    const int bco = blockIdx.x * (32 * TCO), bci = blockIdx.y * (32 * TCI);
-    long p_begin = (long)blockIdx.z * a.per_slab, p_end = p_begin + a.per_slab;
+    const int unit = a.xcd ? xcd_chunk(blockIdx.x, gridDim.x) : (int)blockIdx.x, ntile = a.cot * a.cit;
+    const int slab = unit / ntile, tile = unit - slab * ntile;
+    const int bco = (tile % a.cot) * (32 * TCO), bci = (tile / a.cot) * (32 * TCI);
+    long p_begin = (long)slab * a.per_slab, p_end = p_begin + a.per_slab;
     if (p_end > a.npatch) p_end = a.npatch;
 
     f32x4 acc[NT][TCO][TCI];
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
     }
     // D rows = co ((lane>>4)*4 + r), cols = ci (lane & 15); every slab owns one [Cout][Kpad] partial matrix (plain
     // stores: an atomic flush into one shared matrix ran at ~250 G adds/s and dominated the small layers)
-    float* part = dwp + (long)blockIdx.z * a.Cout * a.Kpad;
+    float* part = dwp + (long)slab * a.Cout * a.Kpad;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -298,6 +309,20 @@ WgPlan make_plan(const WgArgs& a, int k) {
     } else {
         want_blocks = p.ti == 1 ? 512 : 256;                                       // 64 x 32 x 9 vs 64 x 64 x 9 tiles
     }
+    // small layers: no more partial-matrix bytes than `scale` x the operand bytes (the partials of a 20x20 layer were
+    // 5-10x its operands at the counts above: ~65 MB written and read back per layer whatever its size), but never fewer
+    // than `floor` workgroups.  In-step A/B (same box): off 11.75 ms, 0.5/128 11.51, 0.35-0.7 / 96-192 11.55-11.58,
+    // 0.25/64 11.99, 0.125/64 12.77 (too few workgroups: the side stream becomes the critical path)
+    {
+        static const double scale = [] { const char* e = getenv("YOLO_WG_SCALE"); return e ? atof(e) : 0.5; }();
+        if (scale > 0.0 && tu.all_blocks <= 0 && tu.blocks <= 0) {
+            const long tile_bytes = (long)k * k * (32 * p.to) * (32 * p.ti) * 4;
+            long cap = (long)(scale * (double)data_bytes / (double)tile_bytes);
+            static const long floor_wg = [] { const char* e = getenv("YOLO_WG_FLOOR"); return e ? atol(e) : 128L; }();
+            if (cap < floor_wg) cap = floor_wg;
+            if (want_blocks > cap) want_blocks = cap;
+        }
+    }
     long min_per = 2;
     if (tu.to > 0 && (k == 1 || tu.to <= 2)) p.to = tu.to;
     if (tu.ti > 0 && (k == 1 || tu.ti <= 2)) p.ti = tu.ti;
@@ -319,7 +344,10 @@ template <typename T, int KS, int S, int TCO, int TCI>
 void launch(const WgArgs& a, const WgPlan& p, const void* x, const void* dy, float* part, hipStream_t st) {
     WgArgs b = a;
     b.per_slab = p.per_slab;
-    hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI>), dim3(p.cot, p.cit, p.nslab), dim3(256), 0, st, b, (const T*)x,
+    b.cot = p.cot; b.cit = p.cit;
+    static const int xcd = [] { const char* e = getenv("YOLO_WG_XCD"); return e ? atoi(e) : 1; }();
+    b.xcd = xcd;
+    hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI>), dim3((unsigned)(p.cot * p.cit * p.nslab)), dim3(256), 0, st, b, (const T*)x,
                        (const T*)dy, part);
 }
 
