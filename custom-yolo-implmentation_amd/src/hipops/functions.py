@@ -72,12 +72,23 @@ def step_stream(dev):
     return st
 
 
+JOIN_EACH_GROUP = os.environ.get("YOLO_WGRAD_JOIN", "1") == "1"
+
+
 def _issue_wgrads(dev, cur, side):
-    """One sync point: join what runs on the side stream, fork, issue every queued piece of work there."""
-    if _INFLIGHT.get(dev):
-        cur.wait_stream(side)
+    """One sync point: join what runs on the side stream, fork, issue every queued piece of work there.
+    The join releases the previous group's inputs (x, dy) and costs the main chain 35-125 us of idle time at most sync
+    points of a step (tools/queue_gaps.py: 0.6-0.9 ms per step: the side stream has not drained yet).  Dropping it
+    (YOLO_WGRAD_JOIN=0: inputs referenced until join_wgrad_stream, one join at the end) was measured SLOWER in the replayed
+    graph, 12.32 vs 11.70 ms per step on the same box, at every group size: the side stream then lags without bound and
+    shares the chip with the main chain all the way through the large-map layers at the end of backward."""
     jobs = _QUEUED.pop(dev, [])
-    _INFLIGHT[dev] = jobs                   # the previous group's inputs may be reused from here on
+    if JOIN_EACH_GROUP:
+        if _INFLIGHT.get(dev):
+            cur.wait_stream(side)
+        _INFLIGHT[dev] = jobs               # the previous group's inputs may be reused from here on
+    else:
+        _INFLIGHT.setdefault(dev, []).extend(jobs)
     if jobs:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
