@@ -554,14 +554,14 @@ static dim3 dw_grid(int nrows, int cv) {
 
 // dwconv.hip: the strip kernels for 16-bit tensors with 8-channel alignment (-1 = does not qualify)
 int dw_strip_launch(bool flip, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
-                    int accumulate, hipStream_t st);
+                    int accumulate, float* stats, hipStream_t st);
 int dw_strip_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* partial, int nslab, int N, int H, int W, int C,
                           int dtype, hipStream_t st);
 
 template <bool FLIP>
 static int dw_launch(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
                      int accumulate, hipStream_t st) {
-    const int fast = dw_strip_launch(FLIP, x, ldx, w, y, ldy, N, H, W, C, dtype, accumulate, st);
+    const int fast = dw_strip_launch(FLIP, x, ldx, w, y, ldy, N, H, W, C, dtype, accumulate, nullptr, st);
     if (fast >= 0) return fast;
     YOLO_DISPATCH_T(dtype, {
         if (vecok<T>(x, ldx, C) && vecok<T>(y, ldy, C)) {
@@ -581,6 +581,15 @@ extern "C" {
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
                        hipStream_t st) {
     return dw_launch<false>(x, ldx, w, y, ldy, N, H, W, C, dtype, 0, st);
+}
+
+// forward that also accumulates the BatchNorm batch statistics of y (sum, sum of squares of the stored values) into
+// stats[8][2][C] (zeroed by the caller; the layout yolo_bn_stats_acc fills).  Returns 1 when the fused kernel does not take
+// these tensors (fp32, unaligned): nothing was launched, the caller runs yolo_dwconv3x3_fwd + yolo_bn_stats_acc.
+int yolo_dwconv3x3_fwd_stats(const void* x, int ldx, const float* w, void* y, int ldy, float* stats, int N, int H, int W, int C,
+                             int dtype, hipStream_t st) {
+    const int fast = dw_strip_launch(false, x, ldx, w, y, ldy, N, H, W, C, dtype, 0, stats, st);
+    return fast < 0 ? 1 : fast;
 }
 
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C,

@@ -55,18 +55,21 @@ __device__ __forceinline__ void stage_taps(float* wl, const float* __restrict__ 
 
 template <typename T, int R, bool FLIP>
 __global__ __launch_bounds__(256) void k_dw3x3_strip(DwGeom g, const T* __restrict__ x, const float* __restrict__ w,
-                                                     T* __restrict__ y, int accumulate) {
+                                                     T* __restrict__ y, int accumulate, float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int c0 = blockIdx.y * g.cvb * 8;
     stage_taps<FLIP>(wl, w, c0, g.C, g.cvb);
     __syncthreads();
     const int cgl = threadIdx.x % g.cvb, col = threadIdx.x / g.cvb;
     const int ch = c0 + cgl * 8;
-    if (col >= g.ncol || ch >= g.C) return;
+    const bool active = col < g.ncol && ch < g.C;
+    float ssum[8], ssq[8];                                   // BatchNorm batch statistics of the stored (rounded) values
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, g.N * g.H * g.W * g.ldx * 2, 0x00020000);
     const float4* wq = reinterpret_cast<const float4*>(wl) + cgl;
-    for (long s = blockIdx.x; s < g.total; s += gridDim.x) {
+    for (long s = blockIdx.x; active && s < g.total; s += gridDim.x) {
         const int cbk = (int)(s % g.ncb);
         const long t2 = s / g.ncb;
         const int sh = (int)(t2 % g.nsh), n = (int)(t2 / g.nsh);
@@ -118,6 +121,33 @@ __global__ __launch_bounds__(256) void k_dw3x3_strip(DwGeom g, const T* __restri
                 for (int j = 0; j < 8; ++j) acc[o][j] += prev[j];
             }
             store_pack<T, 8>(dst, acc[o]);
+            if (!FLIP && stats != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float r2 = to_f<T>(from_f<T>(acc[o][j]));
+                    ssum[j] += r2;
+                    ssq[j] += r2 * r2;
+                }
+            }
+        }
+    }
+    if (FLIP || stats == nullptr) return;
+    // workgroup totals per channel (the columns of one channel group through LDS), then one atomic per channel and
+    // statistic into replica (workgroup index mod 8) of the [8][2][C] accumulator -- the forward of a BatchNorm conv
+    // needs no separate statistics pass over y
+    __shared__ float red[256][9];
+    float* o = stats + (long)(blockIdx.x & 7) * 2 * g.C;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = active ? (pass ? ssq[j] : ssum[j]) : 0.f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < g.cvb * 8; e += 256) {
+            const int cl = e >> 3, j = e & 7;
+            float t = 0.f;
+            for (int cc = 0; cc < g.ncol; ++cc) t += red[cc * g.cvb + cl][j];
+            if (c0 + e < g.C) atomicAdd(o + pass * g.C + c0 + e, t);
         }
     }
 }
@@ -219,14 +249,14 @@ bool dw_geom(DwGeom& g, const void* x, int ldx, const void* y, int ldy, int N, i
 
 // forward / data gradient; returns -1 when the tensors do not qualify (the caller falls back to the generic kernel)
 int dw_strip_launch(bool flip, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
-                    int accumulate, hipStream_t st) {
+                    int accumulate, float* stats, hipStream_t st) {
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return -1;
     constexpr int R = 4;
     DwGeom g;
     if (!dw_geom(g, x, ldx, y, ldy, N, H, W, C, R)) return -1;
     const dim3 grid((unsigned)(g.total < 4096 ? g.total : 4096), (unsigned)ceil_div(C / 8, g.cvb));
     const size_t lds = (size_t)g.cvb * 8 * 9 * sizeof(float);
-#define DW_GO(T_, FLIP_) hipLaunchKernelGGL((k_dw3x3_strip<T_, R, FLIP_>), grid, dim3(256), lds, st, g, (const T_*)x, w, (T_*)y, accumulate)
+#define DW_GO(T_, FLIP_) hipLaunchKernelGGL((k_dw3x3_strip<T_, R, FLIP_>), grid, dim3(256), lds, st, g, (const T_*)x, w, (T_*)y, accumulate, stats)
     if (dtype == YOLO_BF16) { if (flip) DW_GO(bf16_t, true); else DW_GO(bf16_t, false); }
     else { if (flip) DW_GO(f16_t, true); else DW_GO(f16_t, false); }
 #undef DW_GO

@@ -322,9 +322,7 @@ class ConvBnAct(torch.autograd.Function):
             y = ops.conv_fwd(x, ops.stem_pack_weights(weight, T), None, cout, 1, 1, acc_f)
         elif depthwise:
             x = _as_nhwc(x, T)
-            y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9))
-            if training:
-                ops.bn_stats_acc(y, acc_f)
+            y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9), acc_f if training else None)
         else:
             x = _as_nhwc(x, T)
             y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride, acc_f)

@@ -357,10 +357,20 @@ def stem_unpack_wgrad(dw32, w_dtype, out=None):
     return dw
 
 
-def dw_fwd(x, w9):
+def dw_fwd(x, w9, stats_acc=None):
+    """Depthwise 3x3; with `stats_acc` (a zeroed bn_acc_new buffer) the BatchNorm batch statistics of y are accumulated
+    too -- by the conv kernel itself where it can, else by a statistics pass over y."""
     n, c, h, w, ldx = geom(x)
     y = new_nhwc(n, c, h, w, x.dtype, x.device)
+    if stats_acc is not None:
+        rc = lib.query("yolo_dwconv3x3_fwd_stats", _p(x), ldx, _p(w9), _p(y), c, _p(stats_acc), n, h, w, c, dt(x), _stream(x))
+        if rc == 0:
+            return y
+        if rc != 1:
+            lib.status(rc, "yolo_dwconv3x3_fwd_stats")
     lib.call("yolo_dwconv3x3_fwd", _p(x), ldx, _p(w9), _p(y), c, n, h, w, c, dt(x), _stream(x))
+    if stats_acc is not None:
+        bn_stats_acc(y, stats_acc)
     return y
 
 

@@ -101,6 +101,7 @@ int yolo_stem_wgrad_slabs();
 int yolo_stem_wgrad(const float* img, const void* dy, int ldy, float* partial, void* dw, int dw_dtype, int N, int H, int W, int OH, int OW, int Cout, int dtype, hipStream_t st);
 /* depthwise 3x3 (groups == channels: model_blocks.py:183, head.py:56,58) */
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype, hipStream_t st);
+int yolo_dwconv3x3_fwd_stats(const void* x, int ldx, const float* w, void* y, int ldy, float* stats, int N, int H, int W, int C, int dtype, hipStream_t st);
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int accumulate, int dtype, hipStream_t st);
 int yolo_dw_wgrad_nslab(int N, int H);
 int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* partial, int N, int H, int W, int C, int dtype, hipStream_t st);

@@ -150,9 +150,12 @@ def stem_unpack_wgrad(dw32, w_dtype, out=None):
     return dw32.reshape(dw32.shape[0], 32)[:, :27].reshape(-1, 3, 3, 3).to(w_dtype)
 
 
-def dw_fwd(x, w9):
+def dw_fwd(x, w9, stats_acc=None):
     c = x.shape[1]
-    return _nhwc(F.conv2d(x.float(), w9.view(c, 1, 3, 3), None, 1, 1, 1, c).to(x.dtype))
+    y = _nhwc(F.conv2d(x.float(), w9.view(c, 1, 3, 3), None, 1, 1, 1, c).to(x.dtype))
+    if stats_acc is not None:
+        bn_stats_acc(y, stats_acc)
+    return y
 
 
 def _acc(acc_into, val, dtype):

@@ -212,6 +212,12 @@ def test_depthwise(dtype, c, h, w):
     x, dy = nhwc(rnd(2, c, h, w, seed=20).to(dtype)), nhwc(rnd(2, c, h, w, seed=21).to(dtype), 16)   # dy: slice of a wider buffer
     w9 = rnd(c, 9, seed=22, scale=0.3)
     check(o.dw_fwd(dev(x), w9.to(DEV)), emu.dw_fwd(x, w9), dtype, "dw_fwd")
+    acc = o.bn_acc_new(c, DEV)                                   # forward with the BatchNorm statistics in its epilogue
+    ys = o.dw_fwd(dev(x), w9.to(DEV), acc)
+    assert torch.equal(ys.cpu(), o.dw_fwd(dev(x), w9.to(DEV)).cpu())
+    st, yf = acc.view(o.BN_REPL, 2, c).sum(0).cpu(), ys.float().cpu()
+    want = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))])
+    assert torch.allclose(st, want, rtol=2e-4, atol=1e-3 * float(want.abs().max())), (st - want).abs().max()
     check(o.dw_dgrad(dev(dy), w9.to(DEV)), emu.dw_dgrad(dy, w9), dtype, "dw_dgrad")
     prev = nhwc(rnd(2, c, h, w, seed=23).to(dtype))
     got = o.dw_dgrad(dev(dy), w9.to(DEV), acc_into=dev(prev).clone(memory_format=torch.preserve_format))
