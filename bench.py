@@ -279,7 +279,7 @@ def main():
         # measurement of this kernel group is attached with its source, or null when the file is absent
         traffic, traffic_src = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_final_pmc.json")))
             if pm.get("kernel") == dom:
                 traffic, traffic_src = pm["hbm_bytes_per_launch"], pm["source"]
         except (OSError, ValueError, KeyError):

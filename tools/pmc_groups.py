@@ -7,7 +7,11 @@ GROUPS = [("conv fwd+dgrad (k_conv_mfma, k_conv_ring, k_conv_halo)", ("k_conv_mf
           ("k_bn_act_fwd_train", ("k_bn_act_fwd_train",), 2.0), ("k_channel_acc (BN backward pass 1)", ("k_channel_acc",), 2.0),
           ("k_bn_act_bwd_apply_train", ("k_bn_act_bwd_apply_train",), 2.0), ("k_wgrad2", ("k_wgrad2",), 2.0),
           ("k_wgrad_reduce", ("k_wgrad_reduce",), 2.0), ("gradient fan-in (k_add_n)", ("k_add_n",), 2.0), ("ATen (any)", ("at::native",), 2.0),
-          ("k_copy_channels", ("k_copy_channels",), 2.0)]
+          ("k_copy_channels", ("k_copy_channels",), 2.0),
+          ("depthwise (k_dw3x3_strip, k_dw3x3_wgrad_strip, k_dw_wgrad_finalize)", ("k_dw3x3", "k_dw_wgrad"), 2.0),
+          ("stem (k_stem_conv, k_stem_wgrad)", ("k_stem",), 2.0), ("weight packing (k_pack_tiles)", ("k_pack",), 2.0),
+          ("attention (k_gemm, softmax rows, group copies)", ("k_gemm", "k_softmax", "k_group_copy"), 2.0),
+          ("everything else", ("",), 2.0)]
 steps = float(sys.argv[3])
 
 
@@ -33,3 +37,5 @@ for name, _, corr in GROUPS:
         continue
     f, w, n = fetch[name] * corr * 1024 / 1e9 / steps, write[name] * 1024 / 1e9 / steps, nf[name] / steps
     print(f"| {name} | {n:.0f} | {f:.2f} | {w:.2f} | {f + w:.2f} | {(f + w) * 1e3 / n:.1f} |")
+    tf, tw = (locals().get("tf", 0.0) + f), (locals().get("tw", 0.0) + w)
+print(f"| **all kernels** | | {tf:.2f} | {tw:.2f} | {tf + tw:.2f} | |")
