@@ -475,7 +475,25 @@ int attn_bwd_mfma(const T* qkv, int ldq, const T* d_o, int lddo, const T* d_vp, 
 
 }  // namespace
 
+// attention_fused.hip: flash-style MFMA kernels for dk = 32, dh = 64, <= 448 tokens (stash = row log-sum-exp, fp32)
+int attn_fused_ok(int T_, int dk, int dh, int dtype);
+int attn_fused_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, float* lse, int N, int T_, int heads, float scale,
+                   int dtype, hipStream_t st);
+int attn_fused_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv,
+                   const float* lse, float* Dws, void* dqkv, int lddq, int N, int T_, int heads, float scale, int dtype,
+                   hipStream_t st);
+
 extern "C" {
+
+// the same two sizes for a given head shape: the fused kernels keep only the row log-sum-exp and need one fp32 per row of scratch
+size_t yolo_attn_stash_bytes_for(int N, int T_, int heads, int dk, int dh, int dtype) {
+    if (dtype != YOLO_F32 && !attn_fused_ok(T_, dk, dh, dtype)) return (size_t)N * heads * T_ * round32(T_) * 2;
+    return (size_t)N * heads * T_ * 4;
+}
+size_t yolo_attn_workspace_bytes_for(int N, int T_, int heads, int dk, int dh, int dtype) {
+    if (dtype != YOLO_F32 && !attn_fused_ok(T_, dk, dh, dtype)) return (size_t)N * heads * T_ * round32(T_) * 6;
+    return (size_t)N * heads * T_ * 4;
+}
 
 // bytes kept from forward to backward (fp32: row log-sum-exp; bf16/f16: the probability matrices)
 size_t yolo_attn_stash_bytes(int N, int T_, int heads, int dtype) {
@@ -495,6 +513,8 @@ int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv,
     if (!dims_ok(dk, dh)) return YOLO_ERR_ARG;
     if (dtype != YOLO_F32) {
         if (dk % 8 || dh % 8 || ldq % 8 || ldo % 4 || ldv % 8) return YOLO_ERR_ARG;
+        if (attn_fused_ok(T_, dk, dh, dtype))
+            return attn_fused_fwd(qkv, ldq, o, ldo, vp, ldv, (float*)stash, N, T_, heads, scale, dtype, st);
         if (dtype == YOLO_BF16)
             return attn_fwd_mfma<bf16_t>((const bf16_t*)qkv, ldq, (bf16_t*)o, ldo, (bf16_t*)vp, ldv, (bf16_t*)stash, (float*)ws, N,
                                          T_, heads, dk, dh, scale, dtype, st);
@@ -517,6 +537,9 @@ int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* 
     if (!dims_ok(dk, dh)) return YOLO_ERR_ARG;
     if (dtype != YOLO_F32) {
         if (dk % 8 || dh % 8 || ldq % 8 || lddo % 8 || lddq % 4 || (d_vp && lddv % 8)) return YOLO_ERR_ARG;
+        if (attn_fused_ok(T_, dk, dh, dtype))
+            return attn_fused_bwd(qkv, ldq, o, ldo, d_o, lddo, d_vp, lddv, (const float*)stash, (float*)ws, dqkv, lddq, N, T_, heads,
+                                  scale, dtype, st);
         const size_t n = (size_t)N * heads * T_ * round32(T_);
         float* dP = (float*)ws;
         void* dS = (char*)ws + n * 4;

@@ -522,8 +522,8 @@ def attn_fwd(qkv, heads, dk, dh, scale):
     t = h * w
     o = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
     vp = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
-    stash = torch.empty(lib.query("yolo_attn_stash_bytes", n, t, heads, dt(qkv)), dtype=torch.uint8, device=qkv.device)
-    ws = torch.empty(lib.query("yolo_attn_workspace_bytes", n, t, heads, dt(qkv)), dtype=torch.uint8, device=qkv.device)
+    stash = torch.empty(lib.query("yolo_attn_stash_bytes_for", n, t, heads, dk, dh, dt(qkv)), dtype=torch.uint8, device=qkv.device)
+    ws = torch.empty(lib.query("yolo_attn_workspace_bytes_for", n, t, heads, dk, dh, dt(qkv)), dtype=torch.uint8, device=qkv.device)
     lib.call("yolo_attn_fwd", _p(qkv), ld, _p(o), heads * dh, _p(vp), heads * dh, _p(stash), _p(ws), n, t, heads, dk, dh,
              float(scale), dt(qkv), _stream(qkv))
     return o, vp, stash
@@ -533,7 +533,7 @@ def attn_bwd(qkv, o, d_o, d_vp, stash, heads, dk, dh, scale):
     n, cq, h, w, ld = geom(qkv)
     t = h * w
     dqkv = new_nhwc(n, cq, h, w, qkv.dtype, qkv.device)
-    ws = torch.empty(lib.query("yolo_attn_workspace_bytes", n, t, heads, dt(qkv)), dtype=torch.uint8, device=qkv.device)
+    ws = torch.empty(lib.query("yolo_attn_workspace_bytes_for", n, t, heads, dk, dh, dt(qkv)), dtype=torch.uint8, device=qkv.device)
     lib.call("yolo_attn_bwd", _p(qkv), ld, _p(o), geom(o)[4], _p(d_o), geom(d_o)[4], _p(d_vp),
              geom(d_vp)[4] if d_vp is not None else 0, _p(stash), _p(ws), _p(dqkv), cq, n, t, heads, dk, dh,
              float(scale), dt(qkv), _stream(qkv))

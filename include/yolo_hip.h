@@ -133,6 +133,9 @@ int yolo_upsample2x_bwd(const void* dout, int ldd, void* dx, int ldx, int N, int
 /* ---- PSA attention core (model_blocks.py:186-197) */
 size_t yolo_attn_stash_bytes(int N, int T_, int heads, int dtype);
 size_t yolo_attn_workspace_bytes(int N, int T_, int heads, int dtype);
+/* the same sizes for a given head shape (the fused dk=32 / dh=64 kernels keep only the row log-sum-exp) */
+size_t yolo_attn_stash_bytes_for(int N, int T, int heads, int dk, int dh, int dtype);
+size_t yolo_attn_workspace_bytes_for(int N, int T, int heads, int dk, int dh, int dtype);
 int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, void* stash, void* ws, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
 int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv, const void* stash, void* ws, void* dqkv, int lddq, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
 

@@ -315,9 +315,12 @@ def test_maxpool5_and_upsample(dtype):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("heads,dk,dh,h,w", [(2, 32, 64, 6, 6), (4, 32, 64, 20, 20), (1, 16, 32, 13, 11)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("heads,dk,dh,h,w", [(2, 32, 64, 6, 6), (4, 32, 64, 20, 20), (1, 16, 32, 13, 11), (3, 32, 64, 10, 19),
+                                             (1, 32, 64, 21, 21), (2, 32, 64, 23, 23)])
 def test_attention(dtype, heads, dk, dh, h, w):
+    """16-bit with dk 32 / dh 64 and <= 448 tokens: the fused flash-style kernels (36, 190, 400, 441 tokens = every tile-pair
+    count, partial last tiles and query blocks); 529 tokens and the 16 / 32 head: the batched-GEMM route; fp32: the VALU route"""
     o = ops()
     n = 2
     qkv = nhwc(rnd(n, heads * (2 * dk + dh), h, w, seed=50).to(dtype))
@@ -332,6 +335,8 @@ def test_attention(dtype, heads, dk, dh, h, w):
     dq = o.attn_bwd(dev(qkv), og, dev(d_o), dev(d_v), stash, heads, dk, dh, scale)
     dq_ref = emu.attn_bwd(qkv, o_ref, d_o, d_v, lse_ref, heads, dk, dh, scale)
     check(dq, dq_ref, dtype, "attn dqkv", mult=4.0)
+    dq0 = o.attn_bwd(dev(qkv), og, dev(d_o), None, stash, heads, dk, dh, scale)          # no gradient through the re-gathered v
+    check(dq0, emu.attn_bwd(qkv, o_ref, d_o, None, lse_ref, heads, dk, dh, scale), dtype, "attn dqkv (d_vp None)", mult=4.0)
 
 
 # ------------------------------------------------------------------------------------------ loss
