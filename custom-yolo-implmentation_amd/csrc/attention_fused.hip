@@ -9,10 +9,12 @@
 // 32u + 4g + e (e < 4) | 32u + 16 + 4g + (e - 4).  The A operand of that product (V^T, K^T, dO^T or Q^T: "k" = token
 // rows of a [token][channel] LDS image) comes out of the transposing LDS read with the same pairing (rows 32u + 4g + 0..3
 // and 32u + 16 + 4g + 0..3).  So P goes from the softmax to O = P V, and dS to dQ / dK, without leaving registers.
-//   forward   one workgroup = 64 queries of one (image, head): S^T for all keys (<= 28 tiles of 4 registers), column
-//             softmax (in-lane over tiles, two shuffles across g), O^T = V^T P^T, row log-sum-exp kept for backward
-//   backward  k_attn_bwd_dq (per 64 queries): D = rowsum(dO o O), recompute P from the log-sum-exp, dP^T = V dO^T,
-//             dS = P (dP - D) scale, dQ^T = K^T dS^T;   k_attn_bwd_dkv (per 64 keys): S = Q K^T, P, dP = dO V^T, dS,
+// A workgroup is up to 16 waves x 16 tokens of one (image, head) -- 400 tokens: two workgroups of 13 waves, 256 workgroups
+// for 32 images x 4 heads = one per CU -- and stages what it needs of the head in LDS once (K and V, or Q and dO).
+//   forward   S^T tiles are recomputed rather than kept (one MFMA each): pass 1 column maxima, pass 2 p = exp(s - max)
+//             summed and fed unnormalised to O^T = V^T p^T, O divided by the sum at the end; row log-sum-exp kept
+//   backward  k_attn_bwd_dq (per query block): D = rowsum(dO o O), P recomputed from the log-sum-exp, dP^T = V dO^T,
+//             dS = P (dP - D) scale, dQ^T = K^T dS^T;   k_attn_bwd_dkv (per key block): S = Q K^T, P, dP = dO V^T, dS,
 //             dV^T = dO^T P (+ the gradient of the re-gathered v), dK^T = Q^T dS
 // Reference: src/model/model_blocks.py:186-197.
 #include <cstdlib>
@@ -74,69 +76,73 @@ struct FDims { int N, T, heads, ldq, ldo, ldv; float scale; };
 
 constexpr int DK = 32, DH = 64, CQ = 2 * DK + DH;
 constexpr int LDV = 72, LDK = 32;             // LDS row strides (elements) of 64- and 32-channel token images (wgrad_mfma.hip's)
-constexpr int QB = 64;                         // tokens per workgroup (16 per wave)
 
-// rows [0, rows) x `width` channels starting at column `col0` of this (image, head)'s qkv slice -> LDS image, zeros past T
+// rows [0, rows) x `width` channels starting at column `col0` of this (image, head)'s slice -> LDS image, zeros past T.
+// Eight 16-byte loads per thread in flight (clamped addresses, no branch between them): the first form, one load and one
+// LDS store per loop trip, paid a memory round trip per trip -- 21 trips for the 86 KB a workgroup stages.
 template <typename T, int LD>
 __device__ __forceinline__ void stage_tokens(T* dst, const T* __restrict__ base, long row_stride, int col0, int width, int rows, int Tn) {
-    const int cpr = width / 8;
-    for (int idx = threadIdx.x; idx < rows * cpr; idx += 256) {
-        const int r = idx / cpr, ch = (idx - r * cpr) * 8;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r < Tn) v = *reinterpret_cast<const uint4*>(base + (long)r * row_stride + col0 + ch);
-        *reinterpret_cast<uint4*>(dst + r * LD + ch) = v;
+    const int cpr = width / 8, total = rows * cpr, nthr = blockDim.x;
+    constexpr int U = 8;
+    for (int i0 = threadIdx.x; i0 < total; i0 += nthr * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = i0 + u * nthr;
+            const int r = idx / cpr, ch = (idx - r * cpr) * 8;
+            const int rc = (idx < total && r < Tn) ? r : 0;
+            v[u] = *reinterpret_cast<const uint4*>(base + (long)rc * row_stride + col0 + (idx < total ? ch : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = i0 + u * nthr;
+            if (idx < total) {
+                const int r = idx / cpr, ch = (idx - r * cpr) * 8;
+                *reinterpret_cast<uint4*>(dst + r * LD + ch) = r < Tn ? v[u] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
     }
 }
 
+// One workgroup = blockDim / 64 waves x 16 tokens of one (image, head).  K and V of the head sit in LDS; S^T tiles are
+// recomputed instead of kept (one MFMA each): pass 1 finds the column maxima, pass 2 forms p = exp(s - max), sums it and
+// feeds O^T = V^T p^T with the unnormalised p; O is divided by the sum at the end.
 template <typename T, int NPAIR>
-__global__ __launch_bounds__(256) void k_attn_fwd_fused(FDims a, const T* __restrict__ qkv, T* __restrict__ o, T* __restrict__ vp,
-                                                        float* __restrict__ lse) {
+__global__ __launch_bounds__(1024) void k_attn_fwd_fused(FDims a, const T* __restrict__ qkv, T* __restrict__ o, T* __restrict__ vp,
+                                                         float* __restrict__ lse) {
     typedef typename mm<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Vs = reinterpret_cast<T*>(smem_raw);                   // [NPAIR*32][LDV]
-    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+    constexpr int ROWS = NPAIR * 32;
+    T* Ks = reinterpret_cast<T*>(smem_raw);                   // [ROWS][LDK]
+    T* Vs = Ks + ROWS * LDK;                                  // [ROWS][LDV]
+    const int qb = (blockDim.x >> 6) * 16;
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * qb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
     const T* base = qkv + (long)n * a.T * a.ldq + h * CQ;
-    stage_tokens<T, LDV>(Vs, base, a.ldq, 2 * DK, DH, NPAIR * 32, a.T);
-    // v re-gathered to [token][head*dh] for the positional depthwise conv: this workgroup's 64 tokens
-    for (int idx = threadIdx.x; idx < QB * (DH / 8); idx += 256) {
+    stage_tokens<T, LDK>(Ks, base, a.ldq, DK, DK, ROWS, a.T);
+    stage_tokens<T, LDV>(Vs, base, a.ldq, 2 * DK, DH, ROWS, a.T);
+    const int qrow = q0 + wave * 16 + i16;
+    const bool qok = qrow < a.T;
+    const frag bq = load_frag<T>(base + (long)(qok ? qrow : 0) * a.ldq + g * 8, true);
+    __syncthreads();
+    // v re-gathered to [token][head*dh] for the positional depthwise conv: this workgroup's tokens, from the LDS image
+    for (int idx = threadIdx.x; idx < qb * (DH / 8); idx += blockDim.x) {
         const int r = idx / (DH / 8), ch = (idx - r * (DH / 8)) * 8;
         if (q0 + r < a.T)
-            *reinterpret_cast<uint4*>(vp + ((long)n * a.T + q0 + r) * a.ldv + h * DH + ch) =
-                *reinterpret_cast<const uint4*>(base + (long)(q0 + r) * a.ldq + 2 * DK + ch);
-    }
-    const int qrow = q0 + wave * 16 + i16;
-    const frag bq = load_frag<T>(base + (long)qrow * a.ldq + g * 8, qrow < a.T);
-    f32x4 s[2 * NPAIR];
-#pragma unroll
-    for (int t = 0; t < 2 * NPAIR; ++t) {
-        const int krow = 16 * t + i16;
-        const frag ak = load_frag<T>(base + (long)krow * a.ldq + DK + g * 8, krow < a.T);
-        s[t] = mm<T>::mma(ak, bq, (f32x4){0.f, 0.f, 0.f, 0.f});
+            *reinterpret_cast<uint4*>(vp + ((long)n * a.T + q0 + r) * a.ldv + h * DH + ch) = *reinterpret_cast<const uint4*>(Vs + (q0 + r) * LDV + ch);
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 2 * NPAIR; ++t)
+    for (int t = 0; t < 2 * NPAIR; ++t) {
+        const f32x4 st = mm<T>::mma(*reinterpret_cast<const frag*>(Ks + (16 * t + i16) * LDK + g * 8), bq, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = (16 * t + 4 * g + r < a.T) ? s[t][r] * a.scale : -INFINITY;
-            s[t][r] = v;
-            m = fmaxf(m, v);
-        }
+        for (int r = 0; r < 4; ++r)
+            if (16 * t + 4 * g + r < a.T) m = fmaxf(m, st[r] * a.scale);
+    }
     m = xmax(m);
+    __asm__ volatile("" ::: "memory");                        // pass 2 re-reads K: keeping 26 score tiles alive would cost 104 registers
     float l = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2 * NPAIR; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = __expf(s[t][r] - m);
-            s[t][r] = p;
-            l += p;
-        }
-    l = xsum(l);
-    const float inv = 1.f / l;
-    __syncthreads();                                         // V image complete
     f32x4 oacc[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -144,7 +150,16 @@ __global__ __launch_bounds__(256) void k_attn_fwd_fused(FDims a, const T* __rest
     for (int u = 0; u < NPAIR; ++u) {
         float pv[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pv[r] = s[2 * u][r] * inv; pv[4 + r] = s[2 * u + 1][r] * inv; }
+        for (int half = 0; half < 2; ++half) {
+            const int t = 2 * u + half;
+            const f32x4 st = mm<T>::mma(*reinterpret_cast<const frag*>(Ks + (16 * t + i16) * LDK + g * 8), bq, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (16 * t + 4 * g + r < a.T) ? __expf(st[r] * a.scale - m) : 0.f;
+                pv[half * 4 + r] = p;
+                l += p;
+            }
+        }
         const frag pb = pack_frag<T>(pv);
 #pragma unroll
         for (int dt = 0; dt < DH / 16; ++dt) {
@@ -152,48 +167,55 @@ __global__ __launch_bounds__(256) void k_attn_fwd_fused(FDims a, const T* __rest
             oacc[dt] = mm<T>::mma(tr_frag<T>(p, p + 16 * LDV), pb, oacc[dt]);
         }
     }
-    if (qrow < a.T) {
+    l = xsum(l);
+    const float inv = 1.f / l;
+    if (qok) {
         T* orow = o + ((long)n * a.T + qrow) * a.ldo + h * DH;
 #pragma unroll
         for (int dt = 0; dt < DH / 16; ++dt) {
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = oacc[dt][r];
+            for (int r = 0; r < 4; ++r) v[r] = oacc[dt][r] * inv;
             store_pack<T, 4>(orow + dt * 16 + 4 * g, v);
         }
         if (g == 0) lse[((long)n * a.heads + h) * a.T + qrow] = m + __logf(l);
     }
 }
 
-// dQ of 64 queries; also D = rowsum(dO o O) for k_attn_bwd_dkv
+// dQ of the workgroup's queries; also D = rowsum(dO o O) for k_attn_bwd_dkv.  K and V of the head in LDS.
 template <typename T, int NPAIR>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(FDims a, const T* __restrict__ qkv, const T* __restrict__ o,
-                                                     const T* __restrict__ d_o, int lddo, const float* __restrict__ lse,
-                                                     float* __restrict__ Dws, T* __restrict__ dqkv, int lddq) {
+__global__ __launch_bounds__(1024) void k_attn_bwd_dq(FDims a, const T* __restrict__ qkv, const T* __restrict__ o,
+                                                      const T* __restrict__ d_o, int lddo, const float* __restrict__ lse,
+                                                      float* __restrict__ Dws, T* __restrict__ dqkv, int lddq) {
     typedef typename mm<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);                   // [NPAIR*32][LDK]
-    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+    constexpr int ROWS = NPAIR * 32;
+    T* Ks = reinterpret_cast<T*>(smem_raw);                   // [ROWS][LDK]
+    T* Vs = Ks + ROWS * LDK;                                  // [ROWS][LDV]
+    const int qb = (blockDim.x >> 6) * 16;
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * qb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
     const T* base = qkv + (long)n * a.T * a.ldq + h * CQ;
-    stage_tokens<T, LDK>(Ks, base, a.ldq, DK, DK, NPAIR * 32, a.T);
+    stage_tokens<T, LDK>(Ks, base, a.ldq, DK, DK, ROWS, a.T);
+    stage_tokens<T, LDV>(Vs, base, a.ldq, 2 * DK, DH, ROWS, a.T);
     const int qrow = q0 + wave * 16 + i16;
     const bool qok = qrow < a.T;
-    const frag bq = load_frag<T>(base + (long)qrow * a.ldq + g * 8, qok);
-    const T* dorow = d_o + ((long)n * a.T + qrow) * lddo + h * DH;
-    const T* orow = o + ((long)n * a.T + qrow) * a.ldo + h * DH;
+    const int qc = qok ? qrow : 0;
+    const frag bq = load_frag<T>(base + (long)qc * a.ldq + g * 8, true);
+    const T* dorow = d_o + ((long)n * a.T + qc) * lddo + h * DH;
+    const T* orow = o + ((long)n * a.T + qc) * a.ldo + h * DH;
     frag bdo[2];
     float dpart = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        bdo[kk] = load_frag<T>(dorow + kk * 32 + g * 8, qok);
-        const frag of = load_frag<T>(orow + kk * 32 + g * 8, qok);
+        bdo[kk] = load_frag<T>(dorow + kk * 32 + g * 8, true);
+        const frag of = load_frag<T>(orow + kk * 32 + g * 8, true);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dpart += to_f<T>(bdo[kk][e]) * to_f<T>(of[e]);
     }
     const float Dq = xsum(dpart);
-    const float lq = qok ? lse[((long)n * a.heads + h) * a.T + qrow] : 0.f;
+    const float lq = lse[((long)n * a.heads + h) * a.T + qc];
     if (qok && g == 0) Dws[((long)n * a.heads + h) * a.T + qrow] = Dq;
     __syncthreads();
     f32x4 dqacc[DK / 16];
@@ -204,12 +226,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(FDims a, const T* __restric
         float dsv[8];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int t = 2 * u + half, krow = 16 * t + i16;
-            const bool kok = krow < a.T;
-            const T* kr = base + (long)krow * a.ldq;
-            const f32x4 st = mm<T>::mma(load_frag<T>(kr + DK + g * 8, kok), bq, (f32x4){0.f, 0.f, 0.f, 0.f});
-            f32x4 dpt = mm<T>::mma(load_frag<T>(kr + 2 * DK + g * 8, kok), bdo[0], (f32x4){0.f, 0.f, 0.f, 0.f});
-            dpt = mm<T>::mma(load_frag<T>(kr + 2 * DK + 32 + g * 8, kok), bdo[1], dpt);
+            const int t = 2 * u + half;
+            const f32x4 st = mm<T>::mma(*reinterpret_cast<const frag*>(Ks + (16 * t + i16) * LDK + g * 8), bq, (f32x4){0.f, 0.f, 0.f, 0.f});
+            const T* vr = Vs + (16 * t + i16) * LDV + g * 8;
+            f32x4 dpt = mm<T>::mma(*reinterpret_cast<const frag*>(vr), bdo[0], (f32x4){0.f, 0.f, 0.f, 0.f});
+            dpt = mm<T>::mma(*reinterpret_cast<const frag*>(vr + 32), bdo[1], dpt);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = qok && (16 * t + 4 * g + r < a.T);
@@ -236,11 +257,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(FDims a, const T* __restric
     }
 }
 
-// dK, dV of 64 keys
+// dK, dV of the workgroup's keys.  Q and dO of the head (and the rows' log-sum-exp and D) in LDS.
 template <typename T, int NPAIR>
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(FDims a, const T* __restrict__ qkv, const T* __restrict__ d_o, int lddo,
-                                                      const T* __restrict__ d_vp, int lddv, const float* __restrict__ lse,
-                                                      const float* __restrict__ Dws, T* __restrict__ dqkv, int lddq) {
+__global__ __launch_bounds__(1024) void k_attn_bwd_dkv(FDims a, const T* __restrict__ qkv, const T* __restrict__ d_o, int lddo,
+                                                       const T* __restrict__ d_vp, int lddv, const float* __restrict__ lse,
+                                                       const float* __restrict__ Dws, T* __restrict__ dqkv, int lddq) {
     typedef typename mm<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int ROWS = NPAIR * 32;
@@ -248,25 +269,26 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(FDims a, const T* __restri
     T* dOs = Qs + ROWS * LDK;                                 // [ROWS][LDV]
     float* ls = reinterpret_cast<float*>(dOs + ROWS * LDV);   // [ROWS] log-sum-exp, [ROWS] D
     float* Ds = ls + ROWS;
-    const int n = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * QB;
+    const int kb = (blockDim.x >> 6) * 16;
+    const int n = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * kb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
     const T* base = qkv + (long)n * a.T * a.ldq + h * CQ;
     const T* dobase = d_o + (long)n * a.T * lddo + h * DH;
     stage_tokens<T, LDK>(Qs, base, a.ldq, 0, DK, ROWS, a.T);
     stage_tokens<T, LDV>(dOs, dobase, lddo, 0, DH, ROWS, a.T);
-    for (int r = threadIdx.x; r < ROWS; r += 256) {
+    for (int r = threadIdx.x; r < ROWS; r += blockDim.x) {
         const bool ok = r < a.T;
         ls[r] = ok ? lse[((long)n * a.heads + h) * a.T + r] : 0.f;
         Ds[r] = ok ? Dws[((long)n * a.heads + h) * a.T + r] : 0.f;
     }
     const int krow = k0 + wave * 16 + i16;
     const bool kok = krow < a.T;
-    const T* kr = base + (long)krow * a.ldq;
-    const frag bk = load_frag<T>(kr + DK + g * 8, kok);
+    const T* kr = base + (long)(kok ? krow : 0) * a.ldq;
+    const frag bk = load_frag<T>(kr + DK + g * 8, true);
     frag bv[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) bv[kk] = load_frag<T>(kr + 2 * DK + kk * 32 + g * 8, kok);
+    for (int kk = 0; kk < 2; ++kk) bv[kk] = load_frag<T>(kr + 2 * DK + kk * 32 + g * 8, true);
     __syncthreads();
     f32x4 dvacc[DH / 16], dkacc[DK / 16];
 #pragma unroll
@@ -331,6 +353,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(FDims a, const T* __restri
     }
 }
 
+// token blocks per (image, head) and waves per workgroup: as few workgroups as 16 waves allow, equal shares
+void blocking(int Tn, int& nblk, int& waves) {
+    const int tiles = (Tn + 15) / 16;
+    nblk = (tiles + 15) / 16;
+    waves = (tiles + nblk - 1) / nblk;
+}
+
 int npair_for(int Tn) { return Tn <= 128 ? 4 : Tn <= 224 ? 7 : Tn <= 416 ? 13 : 14; }
 
 template <typename F> int opt_in_lds(F* fn, size_t bytes) {
@@ -340,24 +369,28 @@ template <typename F> int opt_in_lds(F* fn, size_t bytes) {
 
 template <typename T, int NPAIR>
 int fwd_go(const FDims& a, const T* qkv, T* o, T* vp, float* lse, hipStream_t st) {
-    const size_t lds = (size_t)NPAIR * 32 * LDV * sizeof(T);
+    const size_t lds = (size_t)NPAIR * 32 * (LDK + LDV) * sizeof(T);
     int rc = opt_in_lds(k_attn_fwd_fused<T, NPAIR>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_attn_fwd_fused<T, NPAIR>), dim3(ceil_div(a.T, QB), a.heads, a.N), dim3(256), lds, st, a, qkv, o, vp, lse);
+    int nblk, waves;
+    blocking(a.T, nblk, waves);
+    hipLaunchKernelGGL((k_attn_fwd_fused<T, NPAIR>), dim3(nblk, a.heads, a.N), dim3(64 * waves), lds, st, a, qkv, o, vp, lse);
     return YOLO_LAUNCH_CHECK();
 }
 
 template <typename T, int NPAIR>
 int bwd_go(const FDims& a, const T* qkv, const T* o, const T* d_o, int lddo, const T* d_vp, int lddv, const float* lse, float* Dws,
            T* dqkv, int lddq, hipStream_t st) {
-    const size_t lds_q = (size_t)NPAIR * 32 * LDK * sizeof(T);
+    const size_t lds_q = (size_t)NPAIR * 32 * (LDK + LDV) * sizeof(T);
     const size_t lds_kv = (size_t)NPAIR * 32 * (LDK + LDV) * sizeof(T) + (size_t)NPAIR * 32 * 2 * sizeof(float);
     int rc = opt_in_lds(k_attn_bwd_dq<T, NPAIR>, lds_q);
     if (!rc) rc = opt_in_lds(k_attn_bwd_dkv<T, NPAIR>, lds_kv);
     if (rc) return rc;
-    const dim3 grid(ceil_div(a.T, QB), a.heads, a.N);
-    hipLaunchKernelGGL((k_attn_bwd_dq<T, NPAIR>), grid, dim3(256), lds_q, st, a, qkv, o, d_o, lddo, lse, Dws, dqkv, lddq);
-    hipLaunchKernelGGL((k_attn_bwd_dkv<T, NPAIR>), grid, dim3(256), lds_kv, st, a, qkv, d_o, lddo, d_vp, lddv, lse, Dws, dqkv, lddq);
+    int nblk, waves;
+    blocking(a.T, nblk, waves);
+    const dim3 grid(nblk, a.heads, a.N), block(64 * waves);
+    hipLaunchKernelGGL((k_attn_bwd_dq<T, NPAIR>), grid, block, lds_q, st, a, qkv, o, d_o, lddo, lse, Dws, dqkv, lddq);
+    hipLaunchKernelGGL((k_attn_bwd_dkv<T, NPAIR>), grid, block, lds_kv, st, a, qkv, d_o, lddo, d_vp, lddv, lse, Dws, dqkv, lddq);
     return YOLO_LAUNCH_CHECK();
 }
 
