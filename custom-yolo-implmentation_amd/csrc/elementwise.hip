@@ -51,6 +51,57 @@ __global__ void k_nhwc_to_ncm(const TI* __restrict__ src, int ld, TO* __restrict
     }
 }
 
+// The head's six branch outputs <-> the (N, no, M) prediction tensor in ONE launch each way (HeadPack): a problem table in
+// the kernel arguments, a workgroup finds its branch from the prefix of tile counts and transposes one 32 x 32 tile.
+constexpr int HEAD_GROUP = 8;
+struct HeadGroup {
+    void* t[HEAD_GROUP];            // NHWC branch tensors
+    int ld[HEAD_GROUP], C[HEAD_GROUP], HW[HEAD_GROUP], c_off[HEAD_GROUP], m_off[HEAD_GROUP], tp[HEAD_GROUP];   // tp: pixel tiles
+    int start[HEAD_GROUP + 1];      // first workgroup (per image) of branch i
+    int n;
+};
+
+template <typename T, bool PACK>
+__global__ __launch_bounds__(256) void k_head_group(HeadGroup g, T* __restrict__ preds, long sn, long sc) {
+    __shared__ float tile[32][33];
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < HEAD_GROUP; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.start[i]) bi = i;
+    T* x; int ld, C, HW, c_off, m_off, tp, st;
+#define HG_PICK(I) case I: x = (T*)g.t[I]; ld = g.ld[I]; C = g.C[I]; HW = g.HW[I]; c_off = g.c_off[I]; m_off = g.m_off[I]; tp = g.tp[I]; st = g.start[I]; break;
+    switch (bi) {
+        HG_PICK(1) HG_PICK(2) HG_PICK(3) HG_PICK(4) HG_PICK(5) HG_PICK(6) HG_PICK(7)
+        default: x = (T*)g.t[0]; ld = g.ld[0]; C = g.C[0]; HW = g.HW[0]; c_off = g.c_off[0]; m_off = g.m_off[0]; tp = g.tp[0]; st = g.start[0]; break;
+    }
+#undef HG_PICK
+    const int tl = (int)blockIdx.x - st;
+    const int n = blockIdx.y, p0 = (tl % tp) * 32, c0 = (tl / tp) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    T* pr = preds + n * sn + (long)c_off * sc + m_off;
+    if (PACK) {
+        for (int r = ty; r < 32; r += 8) {
+            const int p = p0 + r, c = c0 + tx;
+            tile[r][tx] = (p < HW && c < C) ? to_f<T>(x[((long)n * HW + p) * ld + c]) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, p = p0 + tx;
+            if (c < C && p < HW) pr[c * sc + p] = from_f<T>(tile[tx][r]);
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, p = p0 + tx;
+            tile[r][tx] = (c < C && p < HW) ? to_f<T>(pr[c * sc + p]) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int p = p0 + r, c = c0 + tx;
+            if (p < HW && c < C) x[((long)n * HW + p) * ld + c] = from_f<T>(tile[tx][r]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // channel-slice copy / accumulate (concat, chunk backward, gradient fan-in)
 // ---------------------------------------------------------------------------------------------
@@ -826,6 +877,31 @@ int yolo_ncm_to_nhwc(const void* src, int src_dtype, long sn, long sc, long off,
         case YOLO_F16:  return ncm_to_nhwc_out<f16_t>(src, sn, sc, off, dst, dst_dtype, ld, N, C, HW, st);
     }
     return YOLO_ERR_DTYPE;
+}
+
+// up to 8 NHWC branch tensors (one dtype) <-> preds (N, cp, M) of the same dtype: branch i occupies channels
+// [c_off[i], c_off[i] + C[i]) and anchors [m_off[i], m_off[i] + HW[i]).  pack != 0: branches -> preds; 0: preds -> branches.
+int yolo_head_group(int pack, int n, void* const* branches, const int* lds, const int* Cs, const int* HWs, const int* c_offs,
+                    const int* m_offs, void* preds, int cp, int M, int N, int dtype, hipStream_t st) {
+    if (n < 1 || n > HEAD_GROUP) return YOLO_ERR_ARG;
+    HeadGroup g;
+    int wgs = 0;
+    for (int i = 0; i < HEAD_GROUP; ++i) {
+        const int j = i < n ? i : 0;
+        g.t[i] = branches[j]; g.ld[i] = lds[j]; g.C[i] = Cs[j]; g.HW[i] = HWs[j]; g.c_off[i] = c_offs[j]; g.m_off[i] = m_offs[j];
+        g.tp[i] = ceil_div(HWs[j], 32);
+        g.start[i] = wgs;
+        if (i < n) wgs += g.tp[i] * ceil_div(Cs[j], 32);
+    }
+    g.start[HEAD_GROUP] = wgs;
+    g.n = n;
+    if (wgs == 0 || N == 0) return YOLO_OK;
+    const dim3 grid((unsigned)wgs, (unsigned)N);
+    YOLO_DISPATCH_T(dtype, {
+        if (pack) hipLaunchKernelGGL((k_head_group<T, true>), grid, dim3(256), 0, st, g, (T*)preds, (long)cp * M, (long)M);
+        else hipLaunchKernelGGL((k_head_group<T, false>), grid, dim3(256), 0, st, g, (T*)preds, (long)cp * M, (long)M);
+    });
+    return YOLO_LAUNCH_CHECK();
 }
 
 int yolo_nhwc_to_ncm(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, long sn, long sc,

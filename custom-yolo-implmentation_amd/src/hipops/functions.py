@@ -691,23 +691,27 @@ class HeadPack(torch.autograd.Function):
         no = levels[0][0].shape[1] + levels[0][1].shape[1]
         m = sum(b.shape[2] * b.shape[3] for b, _ in levels)
         preds = torch.empty((n, no, m), dtype=T, device=branches[0].device)
-        meta, m_off = [], 0
+        meta, m_off, c_offs, m_offs = [], 0, [], []
         for box, cls in levels:
             h, w = box.shape[2], box.shape[3]
-            ops.head_pack(box, preds, 0, m_off)
-            ops.head_pack(cls, preds, box.shape[1], m_off)
+            c_offs += [0, box.shape[1]]
+            m_offs += [m_off, m_off]
             meta.append((box.shape[1], cls.shape[1], h, w, m_off))
             m_off += h * w
+        ops.head_group(branches, preds, c_offs, m_offs, True)             # all branches in one launch
         ctx.meta = meta
         return preds
 
     @staticmethod
     def backward(ctx, dpreds):
         dpreds = dpreds.contiguous()
-        grads = []
+        n = dpreds.shape[0]
+        grads, c_offs, m_offs = [], [], []
         for cb, cc, h, w, m_off in ctx.meta:
-            grads.append(ops.head_unpack(dpreds, 0, cb, m_off, h, w))
-            grads.append(ops.head_unpack(dpreds, cb, cc, m_off, h, w))
+            grads += [ops.new_nhwc(n, cb, h, w, dpreds.dtype, dpreds.device), ops.new_nhwc(n, cc, h, w, dpreds.dtype, dpreds.device)]
+            c_offs += [0, cb]
+            m_offs += [m_off, m_off]
+        ops.head_group(grads, dpreds, c_offs, m_offs, False)
         return tuple(grads)
 
 

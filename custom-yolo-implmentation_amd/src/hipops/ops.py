@@ -99,6 +99,20 @@ def head_unpack(dpreds, c_off, c, m_off, h, w):
     return out
 
 
+def head_group(branches, preds, c_offs, m_offs, pack):
+    """All branch tensors of the head <-> preds (N, no, M) in one launch: branch i occupies channels c_offs[i].. and anchors
+    m_offs[i]..; pack=True writes preds, False fills the (preallocated) branches from it."""
+    import ctypes
+    k = len(branches)
+    assert 1 <= k <= 8 and preds.is_contiguous() and all(b.dtype == preds.dtype for b in branches)
+    n, cp, m = preds.shape
+    gs = [geom(b) for b in branches]
+    i32 = ctypes.c_int * k
+    lib.call("yolo_head_group", int(pack), k, (ctypes.c_void_p * k)(*[b.data_ptr() for b in branches]), i32(*[g[4] for g in gs]),
+             i32(*[g[1] for g in gs]), i32(*[g[2] * g[3] for g in gs]), i32(*c_offs), i32(*m_offs), _p(preds), cp, m, n,
+             dt(preds), _stream(preds))
+
+
 def copy_channels(src, dst, accumulate=False):
     n, c, h, w, lds = geom(src)
     n2, c2, h2, w2, ldd = geom(dst)

@@ -42,6 +42,8 @@ typedef struct ihipStream_t* hipStream_t;
 int yolo_memset0(void* p, size_t bytes, hipStream_t st);
 int yolo_ncm_to_nhwc(const void* src, int src_dtype, long sn, long sc, long off, void* dst, int dst_dtype, int ld, int N, int C, int HW, hipStream_t st);
 int yolo_nhwc_to_ncm(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, long sn, long sc, long off, int N, int C, int HW, hipStream_t st);
+/* HeadPack in one launch each way: up to 8 NHWC branch tensors <-> the (N, no, M) prediction tensor (head.py:87,119) */
+int yolo_head_group(int pack, int n, void* const* branches, const int* lds, const int* Cs, const int* HWs, const int* c_offs, const int* m_offs, void* preds, int cp, int M, int N, int dtype, hipStream_t st);
 int yolo_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, long npix, int C, int accumulate, int dtype, hipStream_t st);
 int yolo_scale_inplace(void* x, long n, int dtype, const float* scale_dev, hipStream_t st);
 /* gradient fan-in: dst = sum of 2..4 channel-slice tensors in one pass (autograd's accumulation where a tensor has several consumers: model_blocks.py:62,92,156,223-224, neck.py:41-44, head.py:87) */

@@ -37,6 +37,15 @@ def head_unpack(dpreds, c_off, c, m_off, h, w):
     return _nhwc(dpreds[:, c_off:c_off + c, m_off:m_off + h * w].reshape(n, c, h, w))
 
 
+def head_group(branches, preds, c_offs, m_offs, pack):
+    for b, c_off, m_off in zip(branches, c_offs, m_offs):
+        n, c, h, w = b.shape
+        if pack:
+            head_pack(b, preds, c_off, m_off)
+        else:
+            b.copy_(preds[:, c_off:c_off + c, m_off:m_off + h * w].reshape(n, c, h, w))
+
+
 def copy_channels(src, dst, accumulate=False):
     if accumulate:
         dst.copy_((dst.float() + src.float()).to(dst.dtype))
@@ -379,7 +388,7 @@ def val_match(rows, count, gt, gt_off, iou_threshold, nc, skip_empty_gt, counter
                              + mc.class_gt.tolist(), dtype=torch.int64)
 
 
-LEAVES = ["to_nhwc", "head_pack", "head_unpack", "copy_channels", "add_n", "bucket_copy", "zero_", "fill_", "pack_weights", "conv_fwd",
+LEAVES = ["to_nhwc", "head_pack", "head_unpack", "head_group", "copy_channels", "add_n", "bucket_copy", "zero_", "fill_", "pack_weights", "conv_fwd",
           "stem_im2col", "stem_pack_weights", "stem_unpack_wgrad", "bn_stats_acc", "bn_finalize_acc", "bn_act_fwd_train", "bn_act_bwd_train",
           "conv_dgrad", "conv_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "bn_train_stats", "bn_eval_coeffs",
           "bn_act_fwd", "bn_act_bwd", "bn_act_bwd_eval", "channel_sum", "maxpool5_fwd", "maxpool5_bwd",

@@ -65,6 +65,30 @@ def check(got, want, dtype, what, scale=None, mult=1.0):
 
 # ------------------------------------------------------------------------------------------ layout / copies
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_group_equals_per_branch_pack_and_unpack(dtype):
+    """all six branch tensors <-> (N, no, M) in one launch == one transposing launch per branch; odd maps, 80 classes"""
+    o = ops()
+    n, shapes = 3, [(9, 7), (5, 4), (3, 2)]
+    branches, c_offs, m_offs, m = [], [], [], 0
+    for i, (h, w) in enumerate(shapes):
+        branches += [dev(nhwc(rnd(n, 64, h, w, seed=60 + i).to(dtype))), dev(nhwc(rnd(n, 80, h, w, seed=70 + i).to(dtype)))]
+        c_offs += [0, 64]
+        m_offs += [m, m]
+        m += h * w
+    want = torch.zeros(n, 144, m, dtype=dtype, device=DEV)
+    for b, c_off, m_off in zip(branches, c_offs, m_offs):
+        o.head_pack(b, want, c_off, m_off)
+    got = torch.zeros_like(want)
+    o.head_group(branches, got, c_offs, m_offs, True)
+    assert torch.equal(got, want)
+    outs = [torch.full_like(b, 5.0) for b in branches]
+    o.head_group(outs, want, c_offs, m_offs, False)
+    for b, x in zip(branches, outs):
+        assert torch.equal(b, x)
+
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_to_nhwc_and_head_pack_roundtrip(dtype):
     o = ops()
     x = rnd(2, 37, 9, 11, seed=1)
