@@ -97,4 +97,5 @@ def test_parquet_dataset_and_loader_yield_the_collate_format(tmp_path):
         for t in targets:
             assert t["boxes"].shape[1] == 5 and t["boxes"].dtype == torch.float32 and "labels" not in t
     images, targets = next(iter(va))
-    assert torch.isfinite(images).all() and targets[0]["name"] == "im0"
+    # the dataset shuffles its rows like the reference's (`df.sample(frac=...)`, global numpy RNG): either order is right
+    assert torch.isfinite(images).all() and sorted(t["name"] for t in targets) == ["im0", "im1"]
