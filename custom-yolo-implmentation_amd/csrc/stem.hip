@@ -89,16 +89,31 @@ __global__ __launch_bounds__(256) void k_stem_conv(const float* __restrict__ img
     const int ow0 = seg * STEM_SEG, iw0 = 2 * ow0 - 1;
     if ((W & 3) == 0) {
         // one 16-byte load per lane = one whole row segment per wave instruction
-        for (int r = wave; r < 3 * STEM_IR; r += 4) {
-            const int ci = r / STEM_IR, ir = r - ci * STEM_IR;
+        // a wave's (up to four) row segments: all loads in flight before the first LDS store (clamped addresses, no branch)
+        constexpr int RPW = (3 * STEM_IR + 3) / 4;
+        float4 v[RPW];
+        float edge[RPW];
+        const int c = lane * 4;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int r = wave + 4 * k, rr = r < 3 * STEM_IR ? r : 0;
+            const int ci = rr / STEM_IR, ir = rr - ci * STEM_IR;
             const int ih = 2 * oh0 + ir - 1;
             const bool rok = ih >= 0 && ih < H;
             const float* src = img + (((long)n * 3 + ci) * H + (rok ? ih : 0)) * (long)W + 2 * ow0;
-            const int c = lane * 4;
-            float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (rok && 2 * ow0 + c < W) v = *reinterpret_cast<const float4*>(src + c);      // W % 4 == 0: all four or none
-            *reinterpret_cast<float4*>(&rows[r][4 + c]) = v;
-            if (lane == 0) rows[r][3] = (rok && ow0 > 0) ? src[-1] : 0.f;
+            const bool cok = 2 * ow0 + c < W;                                               // W % 4 == 0: all four or none
+            v[k] = *reinterpret_cast<const float4*>(src + (cok ? c : 0));
+            if (!(rok && cok)) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            edge[k] = (lane == 0 && ow0 > 0) ? src[-1] : 0.f;
+            if (!rok) edge[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int r = wave + 4 * k;
+            if (r < 3 * STEM_IR) {
+                *reinterpret_cast<float4*>(&rows[r][4 + c]) = v[k];
+                if (lane == 0) rows[r][3] = edge[k];
+            }
         }
     } else {
         for (int idx = tid; idx < 3 * STEM_IR * STEM_ROWW; idx += 256) {
@@ -239,16 +254,30 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ im
         const int ow0 = seg * STEM_SEG, iw0 = 2 * ow0 - 1;
         __syncthreads();                                    // the previous tile's fragments have been read
         if ((W & 3) == 0) {
-            for (int r = wave; r < 3 * STEM_IR; r += 4) {
-                const int ci = r / STEM_IR, ir = r - ci * STEM_IR;
+            constexpr int RPW = (3 * STEM_IR + 3) / 4;            // a wave's row segments: all loads before the first LDS store
+            float4 v[RPW];
+            float edge[RPW];
+            const int c = lane * 4;
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int r = wave + 4 * k, rr = r < 3 * STEM_IR ? r : 0;
+                const int ci = rr / STEM_IR, ir = rr - ci * STEM_IR;
                 const int ih = 2 * oh0 + ir - 1;
                 const bool rok = ih >= 0 && ih < H;
                 const float* src = img + (((long)n * 3 + ci) * H + (rok ? ih : 0)) * (long)W + 2 * ow0;
-                const int c = lane * 4;
-                float4 v = {0.f, 0.f, 0.f, 0.f};
-                if (rok && 2 * ow0 + c < W) v = *reinterpret_cast<const float4*>(src + c);
-                *reinterpret_cast<float4*>(&rows[r][4 + c]) = v;
-                if (lane == 0) rows[r][3] = (rok && ow0 > 0) ? src[-1] : 0.f;
+                const bool cok = 2 * ow0 + c < W;
+                v[k] = *reinterpret_cast<const float4*>(src + (cok ? c : 0));
+                if (!(rok && cok)) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                edge[k] = (lane == 0 && ow0 > 0) ? src[-1] : 0.f;
+                if (!rok) edge[k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int r = wave + 4 * k;
+                if (r < 3 * STEM_IR) {
+                    *reinterpret_cast<float4*>(&rows[r][4 + c]) = v[k];
+                    if (lane == 0) rows[r][3] = edge[k];
+                }
             }
         } else {
             for (int idx = tid; idx < 3 * STEM_IR * STEM_ROWW; idx += 256) {
@@ -261,13 +290,22 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ im
         }
         // dY: 2 rows x 128 pixels x COUT channels, 16-byte chunks; pixels past the row / image end are zeros
         constexpr int CPP = COUT / 8;
-        for (int id = tid; id < 2 * STEM_SEG * CPP; id += 256) {
+        constexpr int DYR = 2 * STEM_SEG * CPP / 256;         // chunks per thread (CPP = COUT / 8: 2 ... 16), all in flight
+        uint4 dv[DYR];
+#pragma unroll
+        for (int k = 0; k < DYR; ++k) {
+            const int id = tid + 256 * k;
             const int px = id / CPP, ch = (id - px * CPP) * 8;
             const int j = px / STEM_SEG, p = px - j * STEM_SEG;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (oh0 + j < OH && ow0 + p < OW)
-                v = *reinterpret_cast<const uint4*>(dy + (((long)n * OH + oh0 + j) * OW + ow0 + p) * (long)ldy + ch);
-            *reinterpret_cast<uint4*>(ys + px * LDY + ch) = v;
+            const bool ok = oh0 + j < OH && ow0 + p < OW;
+            dv[k] = *reinterpret_cast<const uint4*>(dy + (((long)n * OH + (ok ? oh0 + j : 0)) * OW + (ok ? ow0 + p : 0)) * (long)ldy + ch);
+            if (!ok) dv[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < DYR; ++k) {
+            const int id = tid + 256 * k;
+            const int px = id / CPP, ch = (id - px * CPP) * 8;
+            *reinterpret_cast<uint4*>(ys + px * LDY + ch) = dv[k];
         }
         __syncthreads();
 #pragma unroll
