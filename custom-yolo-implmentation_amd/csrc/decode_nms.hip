@@ -19,6 +19,7 @@ namespace {
 constexpr int REG = 16;
 constexpr float MAX_WH = 7680.f;
 constexpr int MAX_NMS = 30000;
+constexpr int NMS_CHUNK = 8;         // images per mask / scan launch (each owns a ns x words bit matrix: 112 MB at 30000 candidates)
 
 template <typename T> __device__ __forceinline__ float rt(float v) { return to_f<T>(from_f<T>(v)); }
 
@@ -103,59 +104,93 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds4, int& total) {
     return base + inc - v;
 }
 
-// one workgroup per image
+// candidates of anchor m: their number (0 / 1, or the passing classes with multi_label), best class and score
+template <typename T>
+__device__ __forceinline__ int cand_eval(const T* __restrict__ yi, int m, int M, int nc, int multi_label, float conf_thres,
+                                         const ClsFilter& filt, float& best, int& bestc) {
+    int cnt = 0;
+    best = -INFINITY;
+    bestc = 0;
+    if (m < M) {
+        for (int c = 0; c < nc; ++c) {
+            float v = to_f<T>(yi[(long)(4 + c) * M + m]);
+            if (multi_label) { if (v > conf_thres && cls_ok(filt, c)) ++cnt; }
+            else if (v > best) { best = v; bestc = c; }
+        }
+        if (!multi_label) cnt = (best > conf_thres && cls_ok(filt, bestc)) ? 1 : 0;
+    }
+    return cnt;
+}
+
+// Order-preserving compaction of the candidates in two passes over the anchors, one workgroup per 256 anchors and
+// image (the first form walked an image's anchors with ONE workgroup: 3.1 ms for 8 images x 33600 anchors x 84 rows,
+// 80 % of the NMS): pass 1 counts per chunk, pass 2 places each chunk behind the sum of the chunks before it.
+template <typename T>
+__global__ __launch_bounds__(256) void k_cand_count(const T* __restrict__ y, int nc, int M, float conf_thres, int multi_label,
+                                                    ClsFilter filt, int nchunk, int* __restrict__ chunk_cnt /*[bs][nchunk]*/) {
+    __shared__ int lds4[4];
+    const int img = blockIdx.y;
+    const T* yi = y + (long)img * (4 + nc) * M;
+    conf_thres = rt<T>(conf_thres);      // torch compares a T tensor with the Python scalar cast to T
+    float best;
+    int bestc, total;
+    const int cnt = cand_eval<T>(yi, blockIdx.x * 256 + threadIdx.x, M, nc, multi_label, conf_thres, filt, best, bestc);
+    block_excl_scan(cnt, lds4, total);
+    if (threadIdx.x == 0) chunk_cnt[(long)img * nchunk + blockIdx.x] = total;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_candidates(const T* __restrict__ y, int nc, int M, float conf_thres,
-                                                    int multi_label, ClsFilter filt, int cap,
+                                                    int multi_label, ClsFilter filt, int cap, int nchunk,
+                                                    const int* __restrict__ chunk_cnt,
                                                     float* __restrict__ rows /*[bs][cap][6]*/,
                                                     int* __restrict__ count /*[bs]*/, int* __restrict__ overflow) {
     __shared__ int lds4[4];
-    const int img = blockIdx.x;
+    __shared__ int sbase;
+    const int img = blockIdx.y;
     const T* yi = y + (long)img * (4 + nc) * M;
     float* out = rows + (long)img * cap * 6;
-    conf_thres = rt<T>(conf_thres);      // torch compares a T tensor with the Python scalar cast to T
-    int base = 0;
-    for (int m0 = 0; m0 < M; m0 += 256) {
-        const int m = m0 + threadIdx.x;
-        int cnt = 0, bestc = 0;
-        float best = -INFINITY;
-        if (m < M) {
+    conf_thres = rt<T>(conf_thres);
+    {   // candidates of the chunks before this one
+        int part = 0;
+        for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) part += chunk_cnt[(long)img * nchunk + c];
+        int tot;
+        block_excl_scan(part, lds4, tot);
+        if (threadIdx.x == 0) sbase = tot;
+        __syncthreads();
+    }
+    const int base = sbase;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float best;
+    int bestc, total;
+    const int cnt = cand_eval<T>(yi, m, M, nc, multi_label, conf_thres, filt, best, bestc);
+    int pos = base + block_excl_scan(cnt, lds4, total);
+    if (cnt > 0) {
+        float cx = to_f<T>(yi[m]), cy = to_f<T>(yi[(long)M + m]);
+        float dw = rt<T>(to_f<T>(yi[2L * M + m]) / 2.f), dh = rt<T>(to_f<T>(yi[3L * M + m]) / 2.f);
+        float x1 = rt<T>(cx - dw), y1 = rt<T>(cy - dh), x2 = rt<T>(cx + dw), y2 = rt<T>(cy + dh);
+        if (!multi_label) {
+            if (pos < cap) {
+                float* r = out + (long)pos * 6;
+                r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = best; r[5] = (float)bestc;
+            }
+        } else {
             for (int c = 0; c < nc; ++c) {
                 float v = to_f<T>(yi[(long)(4 + c) * M + m]);
-                if (multi_label) { if (v > conf_thres && cls_ok(filt, c)) ++cnt; }
-                else if (v > best) { best = v; bestc = c; }
-            }
-            if (!multi_label) cnt = (best > conf_thres && cls_ok(filt, bestc)) ? 1 : 0;
-        }
-        int total;
-        int pos = base + block_excl_scan(cnt, lds4, total);
-        if (cnt > 0) {
-            float cx = to_f<T>(yi[m]), cy = to_f<T>(yi[(long)M + m]);
-            float dw = rt<T>(to_f<T>(yi[2L * M + m]) / 2.f), dh = rt<T>(to_f<T>(yi[3L * M + m]) / 2.f);
-            float x1 = rt<T>(cx - dw), y1 = rt<T>(cy - dh), x2 = rt<T>(cx + dw), y2 = rt<T>(cy + dh);
-            if (!multi_label) {
-                if (pos < cap) {
-                    float* r = out + (long)pos * 6;
-                    r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = best; r[5] = (float)bestc;
-                }
-            } else {
-                for (int c = 0; c < nc; ++c) {
-                    float v = to_f<T>(yi[(long)(4 + c) * M + m]);
-                    if (v > conf_thres && cls_ok(filt, c)) {
-                        if (pos < cap) {
-                            float* r = out + (long)pos * 6;
-                            r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = v; r[5] = (float)c;
-                        }
-                        ++pos;
+                if (v > conf_thres && cls_ok(filt, c)) {
+                    if (pos < cap) {
+                        float* r = out + (long)pos * 6;
+                        r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = v; r[5] = (float)c;
                     }
+                    ++pos;
                 }
             }
         }
-        base += total;
     }
-    if (threadIdx.x == 0) {
-        if (base > cap) { *overflow = 1; base = cap; }
-        count[img] = base;
+    if (blockIdx.x == (unsigned)nchunk - 1 && threadIdx.x == 0) {
+        int n = base + total;
+        if (n > cap) { *overflow = 1; n = cap; }
+        count[img] = n;
     }
 }
 
@@ -186,9 +221,11 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ rows, co
 
 // mask[i][w] bit b: box order[w*64+b] is suppressed by box order[i]  (only j > i)
 __global__ __launch_bounds__(64) void k_mask(const float* __restrict__ rows, const int* __restrict__ count,
-                                             const int* __restrict__ order, int cap, int img, float thr, int agnostic,
-                                             int words, unsigned long long* __restrict__ mask) {
+                                             const int* __restrict__ order, int cap, int img0, float thr, int agnostic,
+                                             int words, long mask_stride, unsigned long long* __restrict__ mask) {
     __shared__ float bx[64][4];
+    const int img = img0 + blockIdx.z;                        // images of one chunk share the launch (own mask each)
+    mask += (long)blockIdx.z * mask_stride;
     int n = count[img];
     if (n > MAX_NMS) n = MAX_NMS;
     const int bi = blockIdx.y, bj = blockIdx.x;
@@ -227,10 +264,12 @@ __global__ __launch_bounds__(64) void k_mask(const float* __restrict__ rows, con
 }
 
 __global__ __launch_bounds__(64) void k_scan(const float* __restrict__ rows, const int* __restrict__ count,
-                                             const int* __restrict__ order, int cap, int img, int words, int max_det,
-                                             const unsigned long long* __restrict__ mask,
+                                             const int* __restrict__ order, int cap, int img0, int words, int max_det,
+                                             long mask_stride, const unsigned long long* __restrict__ mask,
                                              float* __restrict__ out /*[bs][max_det][6]*/, int* __restrict__ out_count) {
     extern __shared__ unsigned long long removed[];
+    const int img = img0 + blockIdx.x;                        // one wave per image, the images of a chunk side by side
+    mask += (long)blockIdx.x * mask_stride;
     int n = count[img];
     if (n > MAX_NMS) n = MAX_NMS;
     const int lane = threadIdx.x;
@@ -457,8 +496,9 @@ size_t yolo_nms_workspace_bytes(int bs, int M, int nc, int multi_label) {
     size_t b = (size_t)bs * cap * 6 * 4;            // rows
     b += (size_t)bs * MAX_NMS * 4;                  // order
     b += ((size_t)bs * 4 + 4 + 15) / 16 * 16;       // count[bs] + overflow
+    b += ((size_t)bs * ((M + 255) / 256) * 4 + 15) / 16 * 16;   // candidates per 256-anchor chunk
     b = (b + 15) / 16 * 16;
-    b += ns * words * 8;                            // mask (one image at a time)
+    b += (size_t)(bs < NMS_CHUNK ? bs : NMS_CHUNK) * ns * words * 8;   // masks of the images that share a launch
     return b;
 }
 
@@ -479,6 +519,9 @@ int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, 
     int* count = (int*)ws;
     int* overflow = count + bs;
     ws += ((size_t)bs * 4 + 4 + 15) / 16 * 16;
+    const int nchunk = (M + 255) / 256;
+    int* chunk_cnt = (int*)ws;
+    ws += ((size_t)bs * nchunk * 4 + 15) / 16 * 16;
     ws = (char*)(((uintptr_t)ws + 15) / 16 * 16);
     unsigned long long* mask = (unsigned long long*)ws;
     ClsFilter filt;
@@ -486,14 +529,22 @@ int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, 
     for (int k = 0; k < n_classes; ++k) filt.ids[k] = classes[k];
     int rc = yolo_zero_async(overflow, 4, st);
     if (rc) return rc;
-    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_candidates<T>), dim3(bs), dim3(256), 0, st, (const T*)y, nc, M, conf_thres,
-                                              multi_label, filt, cap, rows, count, overflow));
+    YOLO_DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((k_cand_count<T>), dim3(nchunk, bs), dim3(256), 0, st, (const T*)y, nc, M, conf_thres, multi_label,
+                           filt, nchunk, chunk_cnt);
+        hipLaunchKernelGGL((k_candidates<T>), dim3(nchunk, bs), dim3(256), 0, st, (const T*)y, nc, M, conf_thres, multi_label,
+                           filt, cap, nchunk, chunk_cnt, rows, count, overflow);
+    });
     hipLaunchKernelGGL(k_rank, dim3(ceil_div(cap, 256), bs), dim3(256), 0, st, rows, count, cap, order);
-    for (int img = 0; img < bs; ++img) {
-        hipLaunchKernelGGL(k_mask, dim3(words, words), dim3(64), 0, st, rows, count, order, cap, img, iou_thres, agnostic,
-                           words, mask);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(64), (size_t)words * 8, st, rows, count, order, cap, img, words, max_det,
-                           mask, out, out_count);
+    // up to NMS_CHUNK images per pair of launches: the serial one-wave scans of different images run side by side
+    // (one image at a time: 0.67 ms per image on the config-5 tensor, 5.4 ms for its batch of 8)
+    const long mask_stride = (long)ns * words;
+    for (int img = 0; img < bs; img += NMS_CHUNK) {
+        const int nimg = bs - img < NMS_CHUNK ? bs - img : NMS_CHUNK;
+        hipLaunchKernelGGL(k_mask, dim3(words, words, nimg), dim3(64), 0, st, rows, count, order, cap, img, iou_thres, agnostic,
+                           words, mask_stride, mask);
+        hipLaunchKernelGGL(k_scan, dim3(nimg), dim3(64), (size_t)words * 8, st, rows, count, order, cap, img, words, max_det,
+                           mask_stride, mask, out, out_count);
     }
     rc = hip_status(hipMemcpyAsync(status, overflow, 4, hipMemcpyDeviceToDevice, st));
     if (rc) return rc;
