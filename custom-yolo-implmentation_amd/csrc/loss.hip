@@ -112,33 +112,52 @@ __device__ __forceinline__ void qfl_elem(float x, float t, float& val, float& dx
     dx = -(t * dpos + (1.f - t) * dneg) * s * om;
 }
 
+// A workgroup walks whole rows (one class / box logit of one image, A anchors): the row's kind is uniform (box-logit rows
+// only get their zero gradient written), no per-element index division, four packets per thread in flight.
 template <typename T, int V>
-__global__ void k_dense(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds, float coef,
-                        double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_dense(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds, float coef,
+                                               double* __restrict__ partial) {
     __shared__ float red[4];
     const int Cp = 4 * REG + d.nc;
-    const long per_n = (long)Cp * d.A;
-    const long total = (long)d.N * per_n / V;
+    const int rows = d.N * Cp, npk = d.A / V;                 // host: A % V == 0
+    constexpr int U = 4;
     float lsum = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long e0 = i * V;
-        int c = (int)((e0 % per_n) / d.A);
-        float g[V];
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int c = row % Cp;
+        const T* pp = preds + (long)row * d.A;
+        T* dp = dpreds ? dpreds + (long)row * d.A : nullptr;
         if (c < 4 * REG) {
+            if (dp) {
+                float z[V];
 #pragma unroll
-            for (int k = 0; k < V; ++k) g[k] = 0.f;
-        } else {
-            float x[V];
-            load_pack<T, V>(preds + e0, x);
+                for (int k = 0; k < V; ++k) z[k] = 0.f;
+                for (int k = threadIdx.x; k < npk; k += 256) store_pack<T, V>(dp + (long)k * V, z);
+            }
+            continue;
+        }
+        for (int k0 = threadIdx.x; k0 < npk; k0 += 256 * U) {
+            pack_t<T, V> raw[U];
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                float v, dx;
-                qfl_elem(x[k], 0.f, v, dx);
-                lsum += v;
-                g[k] = dx * coef;
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                raw[u] = load_raw<T, V>(pp + (long)(k < npk ? k : k0) * V);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                if (k >= npk) break;
+                float x[V], g[V];
+                unpack<T, V>(raw[u], x);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float v, dx;
+                    qfl_elem(x[e], 0.f, v, dx);
+                    lsum += v;
+                    g[e] = dx * coef;
+                }
+                if (dp) store_pack<T, V>(dp + (long)k * V, g);
             }
         }
-        if (dpreds) store_pack<T, V>(dpreds + e0, g);
     }
     lsum = wave_sum(lsum);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
@@ -317,7 +336,7 @@ int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* stride
         if (G > 0) hipLaunchKernelGGL(k_assign, dim3(G), dim3(256), 0, st, A, pbox, gt, gt_img, gt_off, N, idx);
         constexpr int VV = vec_of<T>::N;
         bool vec = (A % VV == 0) && ((uintptr_t)preds % 16 == 0) && (!dpreds || (uintptr_t)dpreds % 16 == 0);
-        int nblk = (int)((elems / (vec ? VV : 1) + 255) / 256);
+        int nblk = N * (4 * REG + nc);                        // rows; a workgroup takes rows blockIdx.x, + gridDim.x, ...
         if (nblk > DENSE_BLOCKS) nblk = DENSE_BLOCKS;
         if (nblk < 1) nblk = 1;
         int rc = yolo_zero_async(partial, DENSE_BLOCKS * sizeof(double), st);
