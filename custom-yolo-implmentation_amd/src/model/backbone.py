@@ -23,16 +23,19 @@ class Backbone(nn.Module):
         self.p5 = nn.Sequential(_down(w[4], w[5]), C3K2(w[5], w[5], depth[3], csp[1], r=2),
                                 SPPF(w[5], w[5]), PSA(w[5], depth[4]))
 
-    def forward(self, x):
+    def forward(self, x, outs=None):
+        """`outs` = (o3, o4, o5): channel slices of the neck's concat buffers (Neck.alloc) that the last conv of stages
+        p3 / p4 / p5 writes straight into, so that the neck's torch.cat needs no copy of a backbone feature."""
+        o3, o4, o5 = outs if outs is not None else (None, None, None)
         # p3 / p4 feed the next stage (a stride-2 Conv) and the neck: that conv's data gradient is ADDED to the neck's
         # gradient in its kernel epilogue (F_.fan2) instead of autograd summing the two
-        p3, l3 = F_.fan2(self.p3(self.p2(self.p1(x))))
-        p4, l4 = F_.fan2(self._stage(self.p4, p3, l3))
-        return F_.stash(p3, l3), F_.stash(p4, l4), self._stage(self.p5, p4, l4)
+        p3, l3 = F_.fan2(self._stage(self.p3, self.p2(self.p1(x)), None, o3))
+        p4, l4 = F_.fan2(self._stage(self.p4, p3, l3, o4))
+        return F_.stash(p3, l3), F_.stash(p4, l4), self._stage(self.p5, p4, l4, o5)
 
     @staticmethod
-    def _stage(seq, x, link):
+    def _stage(seq, x, link, out=None):
         x = seq[0](x, res_link=link)
-        for m in seq[1:]:
+        for m in seq[1:-1]:
             x = m(x)
-        return x
+        return seq[-1](x, out=out) if out is not None else seq[-1](x)

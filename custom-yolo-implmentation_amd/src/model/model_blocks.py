@@ -100,7 +100,7 @@ class C3K2(nn.Module):
         self.conv2 = Conv((2 + n) * h, out_ch, nn.SiLU())
         self.res_m = nn.ModuleList((C3K(h, h) if csp else Residual(h)) for _ in range(n))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         # conv1 and every chained block write straight into the concat buffer conv2 reads
         h = self.conv1.conv.out_channels // 2
         buf = F_.cat_buffer(x, self.conv1.conv.weight, (2 + len(self.res_m)) * h)
@@ -109,7 +109,7 @@ class C3K2(nn.Module):
         parts = [a, b]
         for i, m in enumerate(self.res_m):
             parts.append(m(b_blk if i == 0 else parts[-1], out=buf[:, (2 + i) * h:(3 + i) * h]))
-        return self.conv2(F_.CatInto.apply(buf, *parts))
+        return self.conv2(F_.CatInto.apply(buf, *parts), out=out)
 
 
 class SPPF(nn.Module):
@@ -184,9 +184,9 @@ class PSA(nn.Module):
         self.conv2 = Conv(2 * (ch // 2), ch, nn.SiLU())
         self.res_m = nn.Sequential(*(PSABlock(ch // 2, ch // 128) for _ in range(n)))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         a, b = F_.Chunk2.apply(self.conv1(x), False)
-        return self.conv2(F_.Cat.apply(a, self.res_m(b)))
+        return self.conv2(F_.Cat.apply(a, self.res_m(b)), out=out)
 
 
 class DFL(nn.Module):

@@ -1,5 +1,6 @@
 """Model = Backbone + Neck + Head with the reference's API (src/model/model_builder.py:13-139):
 forward(x) -> (preds[N,64+nc,M], anchors[2,M], strides[1,M]); fuse(); load_weights(); inference()."""
+import os
 from typing import List
 
 import torch
@@ -12,6 +13,9 @@ from src.model.head import Head
 from src.model.model_blocks import Conv
 from src.model.neck import Neck
 from src.utils.model_utils import fuse_conv, non_max_suppression
+
+
+NECK_DIRECT = os.environ.get("YOLO_NECK_DIRECT", "1") == "1"
 
 
 class Model(nn.Module):
@@ -45,10 +49,12 @@ class Model(nn.Module):
         # one zeroed pool for every layer's BatchNorm accumulators of this pass (a single memset)
         F_.BnArena.current = F_.BnArena(x.device, F_.BnArena.elems_for([m.conv.out_channels for m in convs]))
         try:
-            feats = self.net(x)
+            # the neck's concat buffers; the backbone writes p3 / p4 / p5 into them (YOLO_NECK_DIRECT=0: A/B runs)
+            bufs, outs = self.fpn.alloc(x) if NECK_DIRECT else (None, None)
+            feats = self.net(x, outs)
             if self.stage_cut is not None:
                 feats = self.stage_cut(feats)
-            return self.head(list(self.fpn(feats)))
+            return self.head(list(self.fpn(feats, bufs)))
         finally:
             F_.BnArena.current = None
 
