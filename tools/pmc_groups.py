@@ -10,7 +10,7 @@ GROUPS = [("conv fwd+dgrad (k_conv_mfma, k_conv_ring, k_conv_halo)", ("k_conv_mf
           ("k_copy_channels", ("k_copy_channels",), 2.0),
           ("depthwise (k_dw3x3_strip, k_dw3x3_wgrad_strip, k_dw_wgrad_finalize)", ("k_dw3x3", "k_dw_wgrad"), 2.0),
           ("stem (k_stem_conv, k_stem_wgrad)", ("k_stem",), 2.0), ("weight packing (k_pack_tiles)", ("k_pack",), 2.0),
-          ("attention (k_gemm, softmax rows, group copies)", ("k_gemm", "k_softmax", "k_group_copy"), 2.0),
+          ("attention (k_attn_*; k_gemm / softmax rows / group copies on the unfused route)", ("k_attn", "k_gemm", "k_softmax", "k_group_copy"), 2.0),
           ("everything else", ("",), 2.0)]
 steps = float(sys.argv[3])
 
