@@ -36,6 +36,8 @@ struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic i
     int tap_inner;               // MODE 2 K order: 1 = taps innermost, 0 = channel chunks innermost
     int dma;                     // MODE 2 -> 3: tiles go global -> LDS by LDS-DMA instead of through registers
     float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
+    const void* acc2;            // ACC launches: second accumulate source (row stride ld2) or null
+    int ld2;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -73,6 +75,7 @@ inline GeomDev to_dev(const ConvGeom& g) {
     d.sstride = g.sstride; d.ntaps = g.ntaps; d.Kpad = g.Kpad; d.KT = g.Kpad / BK;
     d.dh_pack = d.dw_pack = 0;
     d.stats = g.stats;
+    d.acc2 = g.acc2; d.ld2 = g.ld2;
     d.tap_inner = 0;
     d.dma = 1;      // LDS-DMA staging: level or a few % ahead of register staging on every shape of tools/conv_tune.py
     for (int t = 0; t < g.ntaps; ++t) {

@@ -287,6 +287,9 @@ int grid_for(long total) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+extern "C" int yolo_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, long npix, int C, int accumulate, int dtype,
+                                  hipStream_t st);      // elementwise.hip
+
 int launch_generic(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                    int dtype, hipStream_t st) {
     long total = (long)g.N * g.Hg * g.Wg * g.Cd;
@@ -317,6 +320,8 @@ int run_conv(const ConvGeom& g, const void* src, const void* wm, const float* bi
         return mfma_conv_launch(g, src, wm, bias, dst, accumulate, dtype, st);
     if (algo == 2) return YOLO_ERR_ARG;   // MFMA demanded but the shape is not eligible
     int rc = launch_generic(g, src, wm, bias, dst, accumulate, dtype, st);
+    if (rc == YOLO_OK && accumulate && g.acc2 != nullptr)      // the generic kernels have one accumulate source: add the second
+        rc = yolo_copy_channels(g.acc2, g.ld2, dst, g.ldd, (long)g.N * g.Hd * g.Wd, g.Cd, 1, dtype, st);
     if (rc == YOLO_OK && g.stats)         // the generic kernel has no statistics epilogue: one extra pass over y
         rc = yolo_bn_stats_acc(dst, g.ldd, (long)g.N * g.Hd * g.Wd, g.Cd, dtype, g.stats, st);
     return rc;
@@ -325,6 +330,7 @@ int run_conv(const ConvGeom& g, const void* src, const void* wm, const float* bi
 ConvGeom fwd_geom(int ldx, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride) {
     ConvGeom g;
     g.stats = stats_acc;
+    g.acc2 = nullptr; g.ld2 = 0;
     g.N = N; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lds = ldx;
     g.Hd = OH; g.Wd = OW; g.Cd = Cout; g.ldd = ldy; g.Hg = OH; g.Wg = OW;
     g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = stride;
@@ -338,6 +344,7 @@ ConvGeom fwd_geom(int ldx, int ldy, float* stats_acc, int N, int H, int W, int C
 ConvGeom dgrad_geom(int lddy, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int c) {
     ConvGeom g;
     g.stats = nullptr;
+    g.acc2 = nullptr; g.ld2 = 0;
     g.N = N; g.Hs = OH; g.Ws = OW; g.Cs = Cout; g.lds = lddy;
     g.Hd = H; g.Wd = W; g.Cd = Cin; g.ldd = lddx;
     int kh[9], kw[9];
@@ -430,9 +437,28 @@ int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, v
 }
 
 // dx[N,H,W,Cin] (= or +=) conv^T(dy[N,OH,OW,Cout]); wb = dgrad-packed buffer from yolo_conv_pack_weights(mode 1)
+static int conv2d_dgrad_impl(const void* dy, int lddy, const void* wb, void* dx, int lddx, const void* acc2, int ld2, int N, int H,
+                            int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo,
+                            hipStream_t st);
+
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin,
                       int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo,
                       hipStream_t st) {
+    return conv2d_dgrad_impl(dy, lddy, wb, dx, lddx, nullptr, 0, N, H, W, Cin, OH, OW, Cout, k, stride, accumulate, dtype, algo, st);
+}
+
+// dx = dgrad + dx + acc2: the data gradient accumulated into dx together with a SECOND tensor of dx's shape (row stride ld2)
+// in the same epilogue -- a three-way gradient fan-in (C3K2: the chunk's half feeds the concat and a Residual whose own
+// skip gradient is a third term) without an extra pass.  Stride 1 only.
+int yolo_conv2d_dgrad_acc2(const void* dy, int lddy, const void* wb, void* dx, int lddx, const void* acc2, int ld2, int N, int H,
+                           int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st) {
+    if (stride != 1 || acc2 == nullptr || (ld2 & 3) || (reinterpret_cast<uintptr_t>(acc2) & 7)) return YOLO_ERR_ARG;
+    return conv2d_dgrad_impl(dy, lddy, wb, dx, lddx, acc2, ld2, N, H, W, Cin, OH, OW, Cout, k, stride, 1, dtype, algo, st);
+}
+
+static int conv2d_dgrad_impl(const void* dy, int lddy, const void* wb, void* dx, int lddx, const void* acc2, int ld2, int N, int H,
+                            int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo,
+                            hipStream_t st) {
     if (!supported(k, stride)) return YOLO_ERR_ARG;
     size_t esz = dtype == YOLO_F32 ? 4 : 2;
     int ncls = stride == 2 ? 4 : 1;
@@ -441,6 +467,7 @@ int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int ld
     bool ring = algo != 1 && stride == 2;
     for (int c = 0; c < ncls; ++c) {
         gs[c] = dgrad_geom(lddy, lddx, N, H, W, Cin, OH, OW, Cout, k, stride, c);
+        gs[c].acc2 = acc2; gs[c].ld2 = ld2;
         offs[c] = off;
         ring = ring && ring_conv_eligible(gs[c], dtype, dy, wb, dx);
         off += (long)Cin * gs[c].Kpad;

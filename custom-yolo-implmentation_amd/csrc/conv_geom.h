@@ -20,6 +20,8 @@ struct ConvGeom {
     int dh[9], dw[9];
     int K, Kpad;
     float* stats;   // forward only: [8][2][Cd] fp32 accumulator for BatchNorm batch statistics, or null
+    const void* acc2;   // accumulating launches only: a SECOND tensor (same pixels and channels as dst, row stride ld2) added
+    int ld2;            // to the result as well -- dst = conv + dst + acc2 (C3K2: the chunk's gradient fan-in), or null
 };
 
 static inline int round_up32(int k) { return (k + 31) / 32 * 32; }

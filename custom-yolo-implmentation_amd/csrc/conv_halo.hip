@@ -153,7 +153,8 @@ __global__ __launch_bounds__((TH / 4) * (BN / 64) * 64) void k_conv_halo(GeomDev
         const int oy = y0 + wgm * 4 + i;
         const bool pv = oy < g.Hg && ox < g.Wg;
         if (pv) {
-            T* drow = dst + (((long)n * g.Hd + oy) * (long)g.Wd + ox) * g.ldd;
+            const long pix = ((long)n * g.Hd + oy) * (long)g.Wd + ox;
+            T* drow = dst + pix * g.ldd;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = cd0 + crow + j * 16 + cq;
@@ -166,6 +167,11 @@ __global__ __launch_bounds__((TH / 4) * (BN / 64) * 64) void k_conv_halo(GeomDev
                     load_pack<T, 4>(drow + c, o);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += o[r];
+                    if (g.acc2 != nullptr) {
+                        load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += o[r];
+                    }
                 }
                 store_pack<T, 4>(drow + c, v);
             }

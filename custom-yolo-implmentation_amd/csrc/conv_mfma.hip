@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             if (q < total_pix) {
-                T* drow = dst + (((long)n * g.Hd + a * g.ostep + g.ooff_h) * (long)g.Wd + b * g.ostep + g.ooff_w) * g.ldd;
+                const long pix = ((long)n * g.Hd + a * g.ostep + g.ooff_h) * (long)g.Wd + b * g.ostep + g.ooff_w;
+                T* drow = dst + pix * g.ldd;
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const int c = cd0 + crow + j * 16 + cq;
@@ -291,6 +292,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         load_pack<T, 4>(drow + c, o);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += o[r];
+                        if (g.acc2 != nullptr) {
+                            load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += o[r];
+                        }
                     }
                     store_pack<T, 4>(drow + c, v);
                 }

@@ -31,6 +31,8 @@ struct RingSub {
 struct RingGeom {
     int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd, ostep, sstride, nsub, spt, ntile_n, wm_elems;
     float* stats;
+    const void* acc2;           // ACC launches: second accumulate source (row stride ld2) or null
+    int ld2;
     RingSub sub[4];
 };
 
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(256) void k_conv_ring(RingGeom g, const T* __restri
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             if (q < sb.npix) {
-                T* drow = dst + (((long)n * g.Hd + a * g.ostep + sb.ooff_h) * (long)g.Wd + b * g.ostep + sb.ooff_w) * g.ldd;
+                const long pix = ((long)n * g.Hd + a * g.ostep + sb.ooff_h) * (long)g.Wd + b * g.ostep + sb.ooff_w;
+                T* drow = dst + pix * g.ldd;
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const int c = cd0 + crow + j * 16 + cq;
@@ -225,6 +228,11 @@ __global__ __launch_bounds__(256) void k_conv_ring(RingGeom g, const T* __restri
                         load_pack<T, 4>(drow + c, o);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += o[r];
+                        if (g.acc2 != nullptr) {
+                            load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += o[r];
+                        }
                     }
                     store_pack<T, 4>(drow + c, v);
                 }
@@ -389,6 +397,7 @@ int ring_conv_launch(const ConvGeom* gs, int n, const long* wm_off, long wm_elem
     RingGeom d;
     d.N = g0.N; d.Hs = g0.Hs; d.Ws = g0.Ws; d.Cs = g0.Cs; d.lds = g0.lds; d.Hd = g0.Hd; d.Wd = g0.Wd; d.Cd = g0.Cd; d.ldd = g0.ldd;
     d.ostep = g0.ostep; d.sstride = g0.sstride; d.stats = g0.stats;
+    d.acc2 = g0.acc2; d.ld2 = g0.ld2;
     d.spt = (g0.Cs + t.bk - 1) / t.bk;
     d.ntile_n = (g0.Cd + t.bn - 1) / t.bn;
     d.wm_elems = (int)wm_elems;

@@ -186,11 +186,12 @@ class ResLink:
     `fan=True` (see `fan2`) makes the protocol symmetric for ANY two consumers of an alias: whichever backward runs
     first leaves its gradient in `dres` (and returns it to autograd), the second ADDS its own into that tensor in its
     kernel epilogue and returns None -- autograd never sums, no extra pass over the gradient."""
-    __slots__ = ("dres", "fan")
+    __slots__ = ("dres", "fan", "chunk")
 
     def __init__(self, fan=False):
         self.dres = None
         self.fan = fan
+        self.chunk = None           # ChunkLink of an enclosing C3K2 whose chunk half this alias is (see ChunkLink)
 
     def usable(self, shape, dtype):
         """The gradient left by the first consumer, if the second can accumulate into it."""
@@ -198,6 +199,22 @@ class ResLink:
         if d is None or tuple(d.shape) != tuple(shape) or d.dtype != dtype or not ops.is_nhwc(d):
             return None
         return d
+
+
+CHUNK_LINK = os.environ.get("YOLO_CHUNK_LINK", "1") == "1"     # 0: A/B runs
+
+
+class ChunkLink:
+    """C3K2's second chunk half feeds the concat (gradient = a slice of the concat's gradient, `dst`, known as soon as
+    CatInto.backward ran) AND the first chained block.  The block's entry convs add their data gradients straight into
+    `dst` -- a Residual's conv1 together with the skip gradient (`ops.conv_dgrad(acc_into=dst, acc2=skip gradient)`), a
+    C3K's two 1x1 convs one after the other -- and set `done`; Chunk2.backward then has nothing left to accumulate
+    (one pass over the gradient less per C3K2)."""
+    __slots__ = ("dst", "done")
+
+    def __init__(self):
+        self.dst = None
+        self.done = False
 
 
 class Alias(torch.autograd.Function):
@@ -408,6 +425,20 @@ class ConvBnAct(torch.autograd.Function):
             into = link.usable((n, cin, h, w), T) if link is not None else None
 
             def dgrad():
+                cl = link.chunk if link is not None else None
+                dst = cl.dst if cl is not None else None
+                if dst is not None and stride == 1 and tuple(dst.shape) == (n, cin, h, w) and dst.dtype == T and ops.is_nhwc(dst):
+                    wb = ops.pack_weights(weight, k, stride, 1, T)
+                    if link.fan:                            # C3K entry: both 1x1 convs add into the concat's slice
+                        ops.conv_dgrad(dy, wb, cin, h, w, k, stride, acc_into=into if into is not None else dst)
+                        if into is None:
+                            link.dres = dst
+                        cl.done = True
+                        return None
+                    if into is not None:                    # Residual entry: slice += skip gradient + this data gradient
+                        ops.conv_dgrad(dy, wb, cin, h, w, k, stride, acc_into=dst, acc2=into)
+                        cl.done = True
+                        return None
                 r = ops.conv_dgrad(dy, ops.pack_weights(weight, k, stride, 1, T), cin, h, w, k, stride, acc_into=into)
                 if into is not None:
                     return None                             # already inside the gradient autograd holds for x
@@ -559,8 +590,11 @@ class CatInto(torch.autograd.Function):
     input (a tensor produced elsewhere, e.g. a backbone feature entering the neck) is copied in.  Backward hands
     out slices of the incoming gradient, like Cat."""
 
+    pending = None          # (ChunkLink, index of the part whose gradient slice it wants): set by cat_into, taken by forward
+
     @staticmethod
     def forward(ctx, buf, *xs):
+        ctx.link, CatInto.pending = CatInto.pending, None
         off, cs = 0, []
         for x in xs:
             c = x.shape[1]
@@ -581,7 +615,16 @@ class CatInto(torch.autograd.Function):
         for c in ctx.cs:
             grads.append(dout[:, off:off + c])
             off += c
+        if ctx.link is not None:
+            cl, index = ctx.link
+            cl.dst, cl.done = grads[1 + index], False
         return tuple(grads)
+
+
+def cat_into(buf, parts, chunk_link=None, index=1):
+    """CatInto.apply with a ChunkLink that wants the gradient slice of parts[index]."""
+    CatInto.pending = (chunk_link, index) if chunk_link is not None else None
+    return CatInto.apply(buf, *parts)
 
 
 class Chunk2(torch.autograd.Function):
@@ -592,10 +635,11 @@ class Chunk2(torch.autograd.Function):
     into that buffer in place and the buffer's head IS the result -- one launch instead of an add and two copies."""
 
     @staticmethod
-    def forward(ctx, x, fanout=False):
+    def forward(ctx, x, fanout=False, chunk_link=None):
         x = _as_nhwc(x, x.dtype)
         h = x.shape[1] // 2
         ctx.shape = tuple(x.shape)
+        ctx.chunk_link = chunk_link
         if fanout:
             return x[:, :h], x[:, h:], x[:, h:]
         return x[:, :h], x[:, h:]
@@ -604,12 +648,17 @@ class Chunk2(torch.autograd.Function):
     def backward(ctx, g0, g1, g2=None):
         n, c, h, w = ctx.shape
         half = c // 2
+        cl = ctx.chunk_link
+        if cl is not None:
+            if cl.done:
+                g2 = None                                   # the block's entry convs already added it into g1 (ChunkLink)
+            cl.dst, cl.done = None, False
         if g0 is not None and g1 is not None and g0.dtype == g1.dtype and g0.stride() == g1.stride() \
                 and ops.is_nhwc(g0) and ops.geom(g0)[4] >= c \
                 and g1.data_ptr() == g0.data_ptr() + half * g0.element_size():
             if g2 is not None:
                 ops.copy_channels(_as_nhwc(g2, g1.dtype), g1, accumulate=True)
-            return g0.as_strided((n, c, h, w), g0.stride(), g0.storage_offset()), None
+            return g0.as_strided((n, c, h, w), g0.stride(), g0.storage_offset()), None, None
         ref = g0 if g0 is not None else (g1 if g1 is not None else g2)
         dx = ops.new_nhwc(n, c, h, w, ref.dtype, ref.device)
         for g, sl in ((g0, dx[:, :half]), (g1, dx[:, half:])):
@@ -619,7 +668,7 @@ class Chunk2(torch.autograd.Function):
                 ops.copy_channels(_as_nhwc(g, ref.dtype), sl)
         if g2 is not None:
             ops.copy_channels(_as_nhwc(g2, ref.dtype), dx[:, half:], accumulate=True)
-        return dx, None
+        return dx, None, None
 
 
 class MaxPool5(torch.autograd.Function):

@@ -285,10 +285,18 @@ def bn_act_bwd_train(dout, y, scale, shift, mean, invstd, gamma, act, acc):
     return dy, dgamma, dbeta
 
 
-def conv_dgrad(dy, wb, cin, h, w, k, stride, acc_into=None):
+def conv_dgrad(dy, wb, cin, h, w, k, stride, acc_into=None, acc2=None):
     """Data gradient; with `acc_into` (an NHWC tensor or channel-slice view of the input's shape) it is ADDED to that
-    tensor in the kernel epilogue instead of being written to a new one (returns acc_into)."""
+    tensor in the kernel epilogue instead of being written to a new one (returns acc_into).  `acc2` (stride 1, with
+    acc_into): a second tensor of that shape added in the same epilogue -- acc_into += dgrad + acc2."""
     n, cout, oh, ow, lddy = geom(dy)
+    if acc2 is not None:
+        if acc_into is None or stride != 1 or tuple(acc2.shape) != (n, cin, h, w) or acc2.dtype != dy.dtype \
+                or tuple(acc_into.shape) != (n, cin, h, w) or acc_into.dtype != dy.dtype:
+            raise RuntimeError("conv_dgrad: acc2 needs a stride-1 conv and acc_into / acc2 of the input gradient's shape / dtype")
+        lib.call("yolo_conv2d_dgrad_acc2", _p(dy), lddy, _p(wb), _p(acc_into), geom(acc_into)[4], _p(acc2), geom(acc2)[4], n, h, w,
+                 cin, oh, ow, cout, k, stride, dt(dy), ALGO, _stream(dy))
+        return acc_into
     if acc_into is None:
         dx, accumulate = new_nhwc(n, cin, h, w, dy.dtype, dy.device), 0
     else:

@@ -59,12 +59,13 @@ class Residual(nn.Module):
         self.conv1 = Conv(ch, mid, nn.SiLU(), k=3, p=1)
         self.conv2 = Conv(mid, ch, nn.SiLU(), k=3, p=1)
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, chunk_link=None):
         if not (self.training and torch.is_grad_enabled()):
             return self.conv2(self.conv1(x), x, out=out)
         # conv1's data gradient is accumulated into the residual gradient by its own kernel (F_.ResLink); the alias
         # makes sure the two convs are the only consumers of what they see as x
         xp, link = F_.Alias.apply(x), F_.ResLink()
+        link.chunk = chunk_link
         return self.conv2(self.conv1(xp, res_link=link), xp, out=out, res_link=link)
 
 
@@ -79,11 +80,13 @@ class C3K(nn.Module):
         self.conv3 = Conv(2 * half, out_ch, nn.SiLU())
         self.res_m = nn.Sequential(Residual(half, e=1.0), Residual(half, e=1.0))
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, chunk_link=None):
         # both branches write their half of the concat buffer directly (no torch.cat copy)
         half = self.conv1.conv.out_channels
         buf = F_.cat_buffer(x, self.conv1.conv.weight, 2 * half)
         xa, link = F_.fan2(x)                                 # two 1x1 convs read x: the second data gradient is added to the first
+        if link is not None:
+            link.chunk = chunk_link
         a = self.res_m[1](self.res_m[0](self.conv1(xa, res_link=link)), out=buf[:, :half])
         b = self.conv2(xa, out=buf[:, half:], res_link=link)
         return self.conv3(F_.CatInto.apply(buf, a, b), out=out)
@@ -105,11 +108,14 @@ class C3K2(nn.Module):
         h = self.conv1.conv.out_channels // 2
         buf = F_.cat_buffer(x, self.conv1.conv.weight, (2 + len(self.res_m)) * h)
         # two views of the buffer's head; the second half also feeds the first block (see Chunk2 on fan-out)
-        a, b, b_blk = F_.Chunk2.apply(self.conv1(x, out=buf[:, :2 * h]), True)
+        # ... and the first block's entry convs add their data gradients straight into the concat gradient's slice of b
+        cl = F_.ChunkLink() if (self.training and torch.is_grad_enabled() and F_.CHUNK_LINK) else None
+        a, b, b_blk = F_.Chunk2.apply(self.conv1(x, out=buf[:, :2 * h]), True, cl)
         parts = [a, b]
         for i, m in enumerate(self.res_m):
-            parts.append(m(b_blk if i == 0 else parts[-1], out=buf[:, (2 + i) * h:(3 + i) * h]))
-        return self.conv2(F_.CatInto.apply(buf, *parts), out=out)
+            o = buf[:, (2 + i) * h:(3 + i) * h]
+            parts.append(m(b_blk, out=o, chunk_link=cl) if i == 0 else m(parts[-1], out=o))
+        return self.conv2(F_.cat_into(buf, parts, cl, 1), out=out)
 
 
 class SPPF(nn.Module):

@@ -76,6 +76,8 @@ long yolo_copy_jobs_finalize(void* jobs_host, int njobs);
 int yolo_multi_copy(const void* jobs_dev, int njobs, long nchunks, float scale, hipStream_t st);
 int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
+/* dx = dgrad + dx + acc2 in one epilogue (a three-way gradient fan-in, stride 1): see model_blocks.py C3K2 */
+int yolo_conv2d_dgrad_acc2(const void* dy, int lddy, const void* wb, void* dx, int lddx, const void* acc2, int ld2, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo);
 int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws, void* dw_oihw, int dw_dtype, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
 /* kernel-selection overrides for tuning runs (tools/conv_tune.py, tools/wg_tune.py) and the variant-forcing parity tests

@@ -130,9 +130,11 @@ def bn_act_bwd_train(dout, y, scale, shift, mean, invstd, gamma, act, acc):
     return bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act)
 
 
-def conv_dgrad(dy, wb, cin, h, w, k, stride, acc_into=None):
+def conv_dgrad(dy, wb, cin, h, w, k, stride, acc_into=None, acc2=None):
     n = dy.shape[0]
     dx = torch.nn.grad.conv2d_input((n, cin, h, w), wb.float(), dy.float(), stride, k // 2)
+    if acc2 is not None:
+        dx = dx + acc2.float()
     if acc_into is not None:
         acc_into.data.copy_((acc_into.float() + dx).to(acc_into.dtype))
         return acc_into

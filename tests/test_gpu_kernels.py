@@ -206,6 +206,23 @@ def test_stem_fused_conv(dtype, cout, h, w):
     assert torch.allclose(st, want, rtol=2e-4, atol=1e-3 * float(want.abs().max())), (st - want).abs().max()
 
 
+@pytest.mark.parametrize("dtype,n,cin,cout,h,w,k", [(torch.bfloat16, 2, 64, 64, 20, 20, 3), (torch.bfloat16, 2, 64, 64, 80, 80, 3),
+                                                    (torch.bfloat16, 32, 128, 256, 20, 20, 1), (torch.bfloat16, 3, 24, 40, 9, 11, 3),
+                                                    (torch.float32, 2, 16, 24, 12, 10, 3), (torch.float16, 2, 128, 64, 40, 40, 3)])
+def test_conv_dgrad_with_two_accumulate_sources(dtype, n, cin, cout, h, w, k):
+    """dx = dgrad + dx + acc2 in one epilogue == the three terms summed in fp32 and rounded once; the shapes reach the halo,
+    ring, gather and generic kernels; dx and acc2 are channel slices of wider buffers (as in C3K2's concat gradient)"""
+    o = ops()
+    dy = dev(nhwc(rnd(n, cout, h, w, seed=80).to(dtype)))
+    wt = rnd(cout, cin, k, k, seed=81, scale=0.1)
+    wb = o.pack_weights(wt.to(DEV), k, 1, 1, dtype)
+    dx0, a2 = nhwc(rnd(n, cin, h, w, seed=82).to(dtype), 16), nhwc(rnd(n, cin, h, w, seed=83).to(dtype), 32)
+    plain = o.conv_dgrad(dy, wb, cin, h, w, k, 1).float().cpu()
+    want = (plain + dx0.float() + a2.float()).to(dtype)
+    got = o.conv_dgrad(dy, wb, cin, h, w, k, 1, acc_into=dev(dx0), acc2=dev(a2))
+    check(got, want, dtype, "dgrad + dst + acc2", mult=2.0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cout,h,w,pad", [(16, 32, 32, 0), (32, 17, 23, 16), (64, 640, 322, 0), (48, 9, 515, 0), (96, 6, 6, 16), (128, 34, 258, 0)])
 def test_stem_fused_wgrad(dtype, cout, h, w, pad):
