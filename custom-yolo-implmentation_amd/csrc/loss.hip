@@ -112,51 +112,63 @@ __device__ __forceinline__ void qfl_elem(float x, float t, float& val, float& dx
     dx = -(t * dpos + (1.f - t) * dneg) * s * om;
 }
 
-// A workgroup walks whole rows (one class / box logit of one image, A anchors): the row's kind is uniform (box-logit rows
-// only get their zero gradient written), no per-element index division, four packets per thread in flight.
+// the same with target 0 (every class logit of the dense pass): t * (...) vanishes exactly (every factor is finite), so
+// dropping the positive branch -- a logf and a division per element -- leaves value and gradient bit-identical
+__device__ __forceinline__ void qfl_elem0(float x, float& val, float& dx) {
+    float s = sigm(x);
+    float l1 = logf(1.f - s + QEPS);
+    float om = 1.f - s;
+    val = -(s * s * l1);
+    float dneg = 2.f * s * l1 - s * s / (1.f - s + QEPS);
+    dx = -dneg * s * om;
+}
+
+// Per image the class logits (nc x A) and the box logits (64 x A) are two contiguous regions: the class packets of all
+// images are spread evenly over the grid, four per thread in flight (one 32-bit division per packet finds its image);
+// the box region only gets its zero gradient written.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_dense(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds, float coef,
                                                double* __restrict__ partial) {
     __shared__ float red[4];
     const int Cp = 4 * REG + d.nc;
-    const int rows = d.N * Cp, npk = d.A / V;                 // host: A % V == 0
+    const int P = d.nc * (d.A / V), Z = 4 * REG * (d.A / V);  // packets per image: class region, box region (host: A % V == 0)
+    const int nthr = gridDim.x * 256, gtid = blockIdx.x * 256 + threadIdx.x;
     constexpr int U = 4;
     float lsum = 0.f;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int c = row % Cp;
-        const T* pp = preds + (long)row * d.A;
-        T* dp = dpreds ? dpreds + (long)row * d.A : nullptr;
-        if (c < 4 * REG) {
-            if (dp) {
-                float z[V];
+    const long per_img = (long)Cp * d.A;
+    for (long i0 = gtid; i0 < (long)d.N * P; i0 += (long)nthr * U) {
+        pack_t<T, V> raw[U];
+        long eo[U];
 #pragma unroll
-                for (int k = 0; k < V; ++k) z[k] = 0.f;
-                for (int k = threadIdx.x; k < npk; k += 256) store_pack<T, V>(dp + (long)k * V, z);
-            }
-            continue;
+        for (int u = 0; u < U; ++u) {
+            const long idx = i0 + (long)u * nthr;
+            const long ic = idx < (long)d.N * P ? idx : i0;
+            const int n = (int)(ic / P), off = (int)(ic - (long)n * P);
+            eo[u] = n * per_img + (long)4 * REG * d.A + (long)off * V;
+            raw[u] = load_raw<T, V>(preds + eo[u]);
         }
-        for (int k0 = threadIdx.x; k0 < npk; k0 += 256 * U) {
-            pack_t<T, V> raw[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + 256 * u;
-                raw[u] = load_raw<T, V>(pp + (long)(k < npk ? k : k0) * V);
+        for (int u = 0; u < U; ++u) {
+            if (i0 + (long)u * nthr >= (long)d.N * P) break;
+            float x[V], g[V];
+            unpack<T, V>(raw[u], x);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float v, dx;
+                qfl_elem0(x[e], v, dx);
+                lsum += v;
+                g[e] = dx * coef;
             }
+            if (dpreds) store_pack<T, V>(dpreds + eo[u], g);
+        }
+    }
+    if (dpreds) {
+        float z[V];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + 256 * u;
-                if (k >= npk) break;
-                float x[V], g[V];
-                unpack<T, V>(raw[u], x);
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    float v, dx;
-                    qfl_elem(x[e], 0.f, v, dx);
-                    lsum += v;
-                    g[e] = dx * coef;
-                }
-                if (dp) store_pack<T, V>(dp + (long)k * V, g);
-            }
+        for (int k = 0; k < V; ++k) z[k] = 0.f;
+        for (long idx = gtid; idx < (long)d.N * Z; idx += nthr) {
+            const int n = (int)(idx / Z), off = (int)(idx - (long)n * Z);
+            store_pack<T, V>(dpreds + n * per_img + (long)off * V, z);
         }
     }
     lsum = wave_sum(lsum);
@@ -336,7 +348,7 @@ int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* stride
         if (G > 0) hipLaunchKernelGGL(k_assign, dim3(G), dim3(256), 0, st, A, pbox, gt, gt_img, gt_off, N, idx);
         constexpr int VV = vec_of<T>::N;
         bool vec = (A % VV == 0) && ((uintptr_t)preds % 16 == 0) && (!dpreds || (uintptr_t)dpreds % 16 == 0);
-        int nblk = N * (4 * REG + nc);                        // rows; a workgroup takes rows blockIdx.x, + gridDim.x, ...
+        int nblk = (int)((elems / (vec ? VV : 1) + 255) / 256);
         if (nblk > DENSE_BLOCKS) nblk = DENSE_BLOCKS;
         if (nblk < 1) nblk = 1;
         int rc = yolo_zero_async(partial, DENSE_BLOCKS * sizeof(double), st);
