@@ -102,6 +102,62 @@ __global__ __launch_bounds__(256) void k_head_group(HeadGroup g, T* __restrict__
     }
 }
 
+// The same with 16-byte accesses on both sides (16-bit tensors, C % 8 == 0, HW / M / offsets multiples of 8): a workgroup
+// owns 64 pixels x all C channels of one branch and image; the tile crosses LDS as [pixel][channel] (row stride C + 2
+// elements: the 8 strided 2-byte reads / writes of a transposing thread fall in different banks).
+template <typename T, bool PACK>
+__global__ __launch_bounds__(256) void k_head_group_vec(HeadGroup g, T* __restrict__ preds, long sn, long sc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hg_raw[];
+    T* tile = reinterpret_cast<T*>(hg_raw);                   // [64][C + 2]
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < HEAD_GROUP; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.start[i]) bi = i;
+    T* x; int ld, C, HW, c_off, m_off, st;
+#define HG_PICK(I) case I: x = (T*)g.t[I]; ld = g.ld[I]; C = g.C[I]; HW = g.HW[I]; c_off = g.c_off[I]; m_off = g.m_off[I]; st = g.start[I]; break;
+    switch (bi) {
+        HG_PICK(1) HG_PICK(2) HG_PICK(3) HG_PICK(4) HG_PICK(5) HG_PICK(6) HG_PICK(7)
+        default: x = (T*)g.t[0]; ld = g.ld[0]; C = g.C[0]; HW = g.HW[0]; c_off = g.c_off[0]; m_off = g.m_off[0]; st = g.start[0]; break;
+    }
+#undef HG_PICK
+    const int n = blockIdx.y, p0 = ((int)blockIdx.x - st) * 64;
+    const int LDT = C + 2, cpr = C / 8;                       // 16-byte chunks per pixel row
+    T* pr = preds + n * sn + (long)c_off * sc + m_off;
+    T* xr = x + ((long)n * HW + p0) * ld;
+    const int npx = HW - p0 < 64 ? HW - p0 : 64;              // multiple of 8
+    if (PACK) {
+        for (int i = threadIdx.x; i < npx * cpr; i += 256) {
+            const int p = i / cpr, ch = (i - p * cpr) * 8;
+            const pack_t<T, 8> v = load_raw<T, 8>(xr + (long)p * ld + ch);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[p * LDT + ch + e] = v.v[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * (npx / 8); i += 256) {
+            const int c = i / (npx / 8), pg = (i - c * (npx / 8)) * 8;
+            pack_t<T, 8> v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] = tile[(pg + e) * LDT + c];
+            *reinterpret_cast<pack_t<T, 8>*>(pr + c * sc + p0 + pg) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < C * (npx / 8); i += 256) {
+            const int c = i / (npx / 8), pg = (i - c * (npx / 8)) * 8;
+            const pack_t<T, 8> v = load_raw<T, 8>(pr + c * sc + p0 + pg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[(pg + e) * LDT + c] = v.v[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < npx * cpr; i += 256) {
+            const int p = i / cpr, ch = (i - p * cpr) * 8;
+            pack_t<T, 8> v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] = tile[p * LDT + ch + e];
+            *reinterpret_cast<pack_t<T, 8>*>(xr + (long)p * ld + ch) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // channel-slice copy / accumulate (concat, chunk backward, gradient fan-in)
 // ---------------------------------------------------------------------------------------------
@@ -921,6 +977,32 @@ int yolo_head_group(int pack, int n, void* const* branches, const int* lds, cons
     g.start[HEAD_GROUP] = wgs;
     g.n = n;
     if (wgs == 0 || N == 0) return YOLO_OK;
+    // 16-bit tensors with 8-element alignment everywhere: the 16-byte form, 64 pixels x all channels per workgroup
+    bool vec = dtype != YOLO_F32 && M % 8 == 0 && (reinterpret_cast<uintptr_t>(preds) & 15) == 0;
+    int cmax = 0;
+    for (int i = 0; i < n && vec; ++i) {
+        vec = Cs[i] % 8 == 0 && HWs[i] % 8 == 0 && m_offs[i] % 8 == 0 && lds[i] % 8 == 0 && (reinterpret_cast<uintptr_t>(branches[i]) & 15) == 0;
+        cmax = Cs[i] > cmax ? Cs[i] : cmax;
+    }
+    if (vec && (size_t)64 * (cmax + 2) * 2 <= 48 * 1024) {
+        int w2 = 0;
+        for (int i = 0; i < HEAD_GROUP; ++i) {
+            const int j = i < n ? i : 0;
+            g.start[i] = w2;
+            if (i < n) w2 += ceil_div(HWs[j], 64);
+        }
+        g.start[HEAD_GROUP] = w2;
+        const dim3 grid2((unsigned)w2, (unsigned)N);
+        const size_t lds_bytes = (size_t)64 * (cmax + 2) * 2;
+        if (dtype == YOLO_BF16) {
+            if (pack) hipLaunchKernelGGL((k_head_group_vec<bf16_t, true>), grid2, dim3(256), lds_bytes, st, g, (bf16_t*)preds, (long)cp * M, (long)M);
+            else hipLaunchKernelGGL((k_head_group_vec<bf16_t, false>), grid2, dim3(256), lds_bytes, st, g, (bf16_t*)preds, (long)cp * M, (long)M);
+        } else {
+            if (pack) hipLaunchKernelGGL((k_head_group_vec<f16_t, true>), grid2, dim3(256), lds_bytes, st, g, (f16_t*)preds, (long)cp * M, (long)M);
+            else hipLaunchKernelGGL((k_head_group_vec<f16_t, false>), grid2, dim3(256), lds_bytes, st, g, (f16_t*)preds, (long)cp * M, (long)M);
+        }
+        return YOLO_LAUNCH_CHECK();
+    }
     const dim3 grid((unsigned)wgs, (unsigned)N);
     YOLO_DISPATCH_T(dtype, {
         if (pack) hipLaunchKernelGGL((k_head_group<T, true>), grid, dim3(256), 0, st, g, (T*)preds, (long)cp * M, (long)M);

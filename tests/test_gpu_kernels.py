@@ -65,10 +65,12 @@ def check(got, want, dtype, what, scale=None, mult=1.0):
 
 # ------------------------------------------------------------------------------------------ layout / copies
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_head_group_equals_per_branch_pack_and_unpack(dtype):
-    """all six branch tensors <-> (N, no, M) in one launch == one transposing launch per branch; odd maps, 80 classes"""
+@pytest.mark.parametrize("shapes", [[(9, 7), (5, 4), (3, 2)], [(16, 12), (8, 8), (2, 4)], [(80, 80), (40, 40), (20, 20)]])
+def test_head_group_equals_per_branch_pack_and_unpack(dtype, shapes):
+    """all six branch tensors <-> (N, no, M) in one launch == one transposing launch per branch; odd maps (2-byte form),
+    8-aligned maps incl. the real 80 / 40 / 20 ones (16-byte form, partial last pixel tile), 80 classes"""
     o = ops()
-    n, shapes = 3, [(9, 7), (5, 4), (3, 2)]
+    n = 3
     branches, c_offs, m_offs, m = [], [], [], 0
     for i, (h, w) in enumerate(shapes):
         branches += [dev(nhwc(rnd(n, 64, h, w, seed=60 + i).to(dtype))), dev(nhwc(rnd(n, 80, h, w, seed=70 + i).to(dtype)))]
