@@ -773,8 +773,10 @@ __global__ void k_maxpool5_fwd(const T* __restrict__ x, int ldx, T* __restrict__
             }
         }
         store_pack<T, V>(out + p * ldo + cg * V, best);
+        pack_t<uint8_t, V> pi;                                // the V argmax bytes in one store
 #pragma unroll
-        for (int j = 0; j < V; ++j) idx[p * C + cg * V + j] = (uint8_t)bi[j];
+        for (int j = 0; j < V; ++j) pi.v[j] = (uint8_t)bi[j];
+        *reinterpret_cast<pack_t<uint8_t, V>*>(idx + p * C + cg * V) = pi;
     }
 }
 
