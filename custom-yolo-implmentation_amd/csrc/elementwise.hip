@@ -207,12 +207,17 @@ __global__ void k_add_n(AddSrcs s, T* __restrict__ dst, int ldd, long npix, int 
 //   MODE 0: (sum y, sum y^2)                      -- BN batch statistics / bias gradient
 //   MODE 1: (sum dz, sum dz*y), dz = dout*act'(z), z = y*scale+shift   (the finalize kernel centres it)
 // ---------------------------------------------------------------------------------------------
+// sigmoid for the BatchNorm + SiLU kernels: hardware reciprocal (1 ulp) instead of the IEEE division -- the division
+// expands to ~10 VALU instructions per element (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) and these kernels
+// are co-limited by VALU issue (a wave64 op takes 4 cycles on the 16-lane SIMD): about a quarter of their instructions
+__device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 __device__ __forceinline__ float act_grad(float z, int act) {
     if (act == 0) return 1.f;
-    float s = sigmoidf_(z);
+    float s = sigmoid_rcp(z);
     return s * (1.f + z * (1.f - s));
 }
-__device__ __forceinline__ float act_fwd(float z, int act) { return act == 0 ? z : z * sigmoidf_(z); }
+__device__ __forceinline__ float act_fwd(float z, int act) { return act == 0 ? z : z * sigmoid_rcp(z); }
 
 template <typename T, int V, int MODE>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_channel_reduce(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ 
 // sum (sum dz*yhat = invstd*(sum dz*y - mean*sum dz)) and derives the five constants into LDS; workgroup row 0
 // also writes dgamma / dbeta.  Same arithmetic as k_bn_bwd_finalize (double).
 template <typename T, int V>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 8)))
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
                               const float* __restrict__ scale, const float* __restrict__ shift,
                               const float* __restrict__ gamma, const float* __restrict__ mean,

@@ -209,8 +209,8 @@ def _record_step_calls(cfg, n, res):
         calls["fwd"].add((nn, cin, cout, h, w, k, stride, ldx, o.geom(y)[4], stats_acc is not None))
         return y
 
-    def dgrad(dy, wb, cin, h, w, k, stride, acc_into=None):
-        dx = real[1](dy, wb, cin, h, w, k, stride, acc_into)
+    def dgrad(dy, wb, cin, h, w, k, stride, acc_into=None, acc2=None):
+        dx = real[1](dy, wb, cin, h, w, k, stride, acc_into, acc2)
         nn, cout, _, _, lddy = o.geom(dy)
         calls["dgrad"].add((nn, cin, cout, h, w, k, stride, o.geom(dx)[4], lddy, acc_into is not None))
         return dx

@@ -26,9 +26,9 @@ def conv_calls(preset="s", res=640):
         calls.append(("fwd", x.shape[1], cout, x.shape[2], x.shape[3], k, stride))
         return rf(x, wp, bias, cout, k, stride, stats_acc, out)
 
-    def dgrad(dy, wb, cin, h, w, k, stride, acc_into=None):
+    def dgrad(dy, wb, cin, h, w, k, stride, acc_into=None, acc2=None):
         calls.append(("dgrad", cin, dy.shape[1], h, w, k, stride))
-        return rd(dy, wb, cin, h, w, k, stride, acc_into)
+        return rd(dy, wb, cin, h, w, k, stride, acc_into, acc2)
 
     def wgrad(x, dy, k, stride, w_dtype, out=None):
         calls.append(("wgrad", x.shape[1], dy.shape[1], x.shape[2], x.shape[3], k, stride))
