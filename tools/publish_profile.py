@@ -16,8 +16,8 @@ for l in groups.splitlines():
     m = l.split("|")
     if len(m) > 6:
         try:
-            rows[m[1].strip().strip("*")] = dict(launches_per_step=float(m[2] or 0), fetch_gb=float(m[3]), write_gb=float(m[4]), total_gb=float(m[5]),
-                                                  mb_per_launch=float(m[6] or 0))
+            rows[m[1].strip().strip("*")] = dict(launches_per_step=float(m[2].strip() or 0), fetch_gb=float(m[3]), write_gb=float(m[4]),
+                                                  total_gb=float(m[5]), mb_per_launch=float(m[6].strip() or 0))
         except ValueError:
             pass
 conv = next(v for k, v in rows.items() if k.startswith("conv fwd+dgrad"))
@@ -74,7 +74,7 @@ Against the start of the round (`profiles/r2_pmc_hbm.md`): all kernels {total} G
 reduce 7.2 GB (was 10.13 + 2.41 = 12.5: the operands, 4.6 GB algorithmic, are fetched 0.95x -- XCD-aware (slab, tile) order -- and the
 partial matrices of small layers are capped at half their operand bytes); conv fwd+dgrad {conv['total_gb']} GB = {conv['total_gb'] / 8.69:.2f}x their
 algorithmic 8.69 GB ({conv['mb_per_launch']} MB per launch: the `traffic` of the bench line); the three BatchNorm passes 14.8 GB = their
-algorithmic bytes; no fp32 score / dP tensors of the attention any more; concat copies 0.63 GB (was 0.97: the backbone writes its
-features into the neck's buffers); the stem 0.9 GB (no column tensor: unfold + 1x1 moved 1.5 GB).
+algorithmic bytes; no fp32 score / dP tensors of the attention any more; concat copies {rows.get('k_copy_channels', {}).get('total_gb', 0)} GB (was 0.97: the backbone writes
+its features into the neck's buffers, C3K2's chunk gradient is accumulated by the data-gradient kernels); the stem 0.9 GB (no column tensor: unfold + 1x1 moved 1.5 GB).
 """)
 print("published", sys.argv[1], "->", P)
