@@ -318,7 +318,7 @@ __device__ __forceinline__ void fold_replicas(const float* __restrict__ acc, int
 }
 
 // MODE 0: acc += (sum y, sum y^2).  MODE 1: acc += (sum dz, sum dz*yhat) with z = (y-mean)*invstd*gamma + beta
-template <typename T, int V, int MODE>
+template <typename T, int V, int MODE, int ACT>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             for (int j = 0; j < V; ++j) {
                 if (MODE == 0) { s[j] += a[j]; q[j] += a[j] * a[j]; }
                 else {
-                    float dz = d[j] * act_grad(a[j] * sc[j] + sh[j], act);
+                    float dz = d[j] * act_grad(a[j] * sc[j] + sh[j], ACT);
                     s[j] += dz;
                     q[j] += dz * a[j];            // raw; the apply kernel centres it
                 }
@@ -414,7 +414,7 @@ __global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, in
 // from the statistics accumulator acc[8][2][C] (coalesced loads spread over the workgroup, then LDS); workgroup row 0
 // also publishes mean / invstd / scale / shift and updates the running statistics.  Same arithmetic as
 // k_bn_finalize_acc.
-template <typename T, int V>
+template <typename T, int V, int ACT>
 __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ y, int ldy, const float* __restrict__ acc, float count,
                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
                         float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean_out,
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ 
         unpack<T, V>(pa, a);
         if (res) unpack<T, V>(pt, t);
 #pragma unroll
-        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], act) + (res ? t[j] : 0.f);
+        for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], ACT) + (res ? t[j] : 0.f);
         store_pack<T, V>(out + p * ldo + cg * V, a);
     };
     long p = (long)blockIdx.x * rpb + r;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ 
 // kernel (float atomics into 8 replicas); every workgroup folds the replicas of ITS channels, centres the second
 // sum (sum dz*yhat = invstd*(sum dz*y - mean*sum dz)) and derives the five constants into LDS; workgroup row 0
 // also writes dgamma / dbeta.  Same arithmetic as k_bn_bwd_finalize (double).
-template <typename T, int V>
+template <typename T, int V, int ACT>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
                               const float* __restrict__ scale, const float* __restrict__ shift,
@@ -534,7 +534,7 @@ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __re
         unpack<T, V>(pd, d);
 #pragma unroll
         for (int j = 0; j < V; ++j)
-            d[j] = my[2 * cw + j] * (d[j] * act_grad(a[j] * my[j] + my[cw + j], act)) + my[3 * cw + j] * a[j] + my[4 * cw + j];
+            d[j] = my[2 * cw + j] * (d[j] * act_grad(a[j] * my[j] + my[cw + j], ACT)) + my[3 * cw + j] * a[j] + my[4 * cw + j];
         store_pack<T, V>(dy + p * lddy + cg * V, d);
     };
     long p = (long)blockIdx.x * rpb + r;
@@ -1180,10 +1180,13 @@ static int launch_acc(int mode, const void* y, int ldy, const void* dout, int ld
         PICK_V(T, ok, {
             const RsPlan pl = rs_plan(npix, C / V);
             if (mode == 0)
-                hipLaunchKernelGGL((k_channel_acc<T, V, 0>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)nullptr, 0,
+                hipLaunchKernelGGL((k_channel_acc<T, V, 0, 0>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)nullptr, 0,
+                                   gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr);
+            else if (act)     // the activation is a template parameter: no per-element select between SiLU and identity
+                hipLaunchKernelGGL((k_channel_acc<T, V, 1, 1>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)dout, ldd,
                                    gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr);
             else
-                hipLaunchKernelGGL((k_channel_acc<T, V, 1>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)dout, ldd,
+                hipLaunchKernelGGL((k_channel_acc<T, V, 1, 0>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)dout, ldd,
                                    gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr);
         });
     });
@@ -1210,7 +1213,12 @@ int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, 
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(out, ldout, C) && (!res || vec_ok<T>(res, ldres, C));
         PICK_V(T, ok, {
             const RsPlan pl = rs_plan(npix, C / V);
-            hipLaunchKernelGGL((k_bn_act_fwd_train<T, V>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
+            if (act)
+                hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 1>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
+                               (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr);
+            else
+                hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 0>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
                                (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
                                mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr);
         });
@@ -1232,7 +1240,12 @@ int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ld
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(dout, ldd, C) && vec_ok<T>(dy, lddy, C);
         PICK_V(T, ok, {
             const RsPlan pl = rs_plan(npix, C / V);
-            hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
+            if (act)
+                hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 1>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
+                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
+                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr);
+            else
+                hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 0>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
                                (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
                                dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr);
         });
