@@ -304,36 +304,61 @@ __global__ __launch_bounds__(64) void k_scan(const float* __restrict__ rows, con
 //                    (as double) >= threshold; int64 counters [total_pred, total_gt, tp, fp, fn, class_tp[nc],
 //                    class_fp[nc], class_fn[nc], class_gt[nc]] updated with atomics
 template <typename T>
-__global__ __launch_bounds__(256) void k_val_candidates(const T* __restrict__ y, int nc, int M, float conf,
+__device__ __forceinline__ int val_eval(const T* __restrict__ yi, int m, int M, int nc, float conf, float& best, int& bestc) {
+    best = -INFINITY;
+    bestc = 0;
+    if (m >= M) return 0;
+    for (int c = 0; c < nc; ++c) {
+        const float v = to_f<T>(yi[(long)(4 + c) * M + m]);
+        const float sg = rt<T>(1.f / (1.f + expf(-v)));
+        if (sg > best) { best = sg; bestc = c; }
+    }
+    return best >= conf ? 1 : 0;
+}
+
+// two passes over 256-anchor chunks like the NMS candidates (k_cand_count / k_candidates): count, then place each chunk
+// behind the chunks before it (one workgroup per IMAGE walked 8400 anchors x 80 sigmoids alone)
+template <typename T>
+__global__ __launch_bounds__(256) void k_val_count(const T* __restrict__ y, int nc, int M, float conf, int nchunk,
+                                                   int* __restrict__ chunk_cnt /*[N][nchunk]*/) {
+    __shared__ int lds4[4];
+    const int img = blockIdx.y;
+    float best;
+    int bestc, total;
+    const int keep = val_eval<T>(y + (long)img * (4 + nc) * M, blockIdx.x * 256 + threadIdx.x, M, nc, rt<T>(conf), best, bestc);
+    block_excl_scan(keep, lds4, total);
+    if (threadIdx.x == 0) chunk_cnt[(long)img * nchunk + blockIdx.x] = total;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_val_candidates(const T* __restrict__ y, int nc, int M, float conf, int nchunk,
+                                                        const int* __restrict__ chunk_cnt,
                                                         float* __restrict__ rows /*[N][M][6]*/, int* __restrict__ count) {
     __shared__ int lds4[4];
-    const int img = blockIdx.x;
+    __shared__ int sbase;
+    const int img = blockIdx.y;
     const T* yi = y + (long)img * (4 + nc) * M;
     float* out = rows + (long)img * M * 6;
-    conf = rt<T>(conf);
-    int base = 0;
-    for (int m0 = 0; m0 < M; m0 += 256) {
-        const int m = m0 + threadIdx.x;
-        int keep = 0, bestc = 0;
-        float best = -INFINITY;
-        if (m < M) {
-            for (int c = 0; c < nc; ++c) {
-                const float v = to_f<T>(yi[(long)(4 + c) * M + m]);
-                const float sg = rt<T>(1.f / (1.f + expf(-v)));
-                if (sg > best) { best = sg; bestc = c; }
-            }
-            keep = best >= conf ? 1 : 0;
-        }
-        int total;
-        const int pos = base + block_excl_scan(keep, lds4, total);
-        if (keep) {
-            float* r = out + (long)pos * 6;
-            r[0] = to_f<T>(yi[m]); r[1] = to_f<T>(yi[(long)M + m]); r[2] = to_f<T>(yi[2L * M + m]);
-            r[3] = to_f<T>(yi[3L * M + m]); r[4] = (float)bestc; r[5] = best;
-        }
-        base += total;
+    {
+        int part = 0;
+        for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) part += chunk_cnt[(long)img * nchunk + c];
+        int tot;
+        block_excl_scan(part, lds4, tot);
+        if (threadIdx.x == 0) sbase = tot;
+        __syncthreads();
     }
-    if (threadIdx.x == 0) count[img] = base;
+    const int base = sbase;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float best;
+    int bestc, total;
+    const int keep = val_eval<T>(yi, m, M, nc, rt<T>(conf), best, bestc);
+    const int pos = base + block_excl_scan(keep, lds4, total);
+    if (keep) {
+        float* r = out + (long)pos * 6;
+        r[0] = to_f<T>(yi[m]); r[1] = to_f<T>(yi[(long)M + m]); r[2] = to_f<T>(yi[2L * M + m]);
+        r[3] = to_f<T>(yi[3L * M + m]); r[4] = (float)bestc; r[5] = best;
+    }
+    if (blockIdx.x == (unsigned)nchunk - 1 && threadIdx.x == 0) count[img] = base + total;
 }
 
 __global__ __launch_bounds__(256) void k_val_rank(const float* __restrict__ rows, const int* __restrict__ count, int M,
@@ -553,7 +578,7 @@ int yolo_nms(const void* y, int dtype, int bs, int nc, int M, float conf_thres, 
 
 // ---- validation (train_model.py:14-142, metrics.py:68-157) ----
 size_t yolo_val_workspace_bytes(int N, int M, int top_k) {
-    return (size_t)N * M * 6 * 4 + (size_t)N * top_k * 4 + (size_t)N * 4 + 64;
+    return (size_t)N * M * 6 * 4 + (size_t)N * top_k * 4 + (size_t)N * 4 + 64 + (size_t)N * ((M + 255) / 256) * 4;
 }
 
 // y: decoded head output (N, 4+nc, M) of dtype (yolo_head_decode).  out: fp32 [N][top_k][6] rows
@@ -567,8 +592,14 @@ int yolo_val_select(const void* y, int dtype, int N, int nc, int M, float conf, 
     int* sel = (int*)ws;
     ws += (size_t)N * top_k * 4;
     int* count = (int*)ws;
-    YOLO_DISPATCH_T(dtype, hipLaunchKernelGGL((k_val_candidates<T>), dim3(N), dim3(256), 0, st, (const T*)y, nc, M, conf, rows,
-                                              count));
+    ws += (size_t)N * 4 + 64;
+    int* chunk_cnt = (int*)ws;
+    const int nchunk = (M + 255) / 256;
+    YOLO_DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((k_val_count<T>), dim3(nchunk, N), dim3(256), 0, st, (const T*)y, nc, M, conf, nchunk, chunk_cnt);
+        hipLaunchKernelGGL((k_val_candidates<T>), dim3(nchunk, N), dim3(256), 0, st, (const T*)y, nc, M, conf, nchunk, chunk_cnt,
+                           rows, count);
+    });
     hipLaunchKernelGGL(k_val_rank, dim3(ceil_div(M, 256), N), dim3(256), 0, st, rows, count, M, top_k, sel);
     hipLaunchKernelGGL(k_val_gather, dim3(N), dim3(64), 0, st, rows, count, M, top_k, sel, out, out_count);
     return YOLO_LAUNCH_CHECK();
