@@ -109,6 +109,14 @@ int yolo_adamw_job_fill(void* jobs_host, int index, void* p, int p_dtype, const 
     return YOLO_OK;
 }
 
+// only the gradient pointers of the n records changed (an eager loop's zero_grad(set_to_none=True) hands autograd fresh
+// gradient tensors every step): one call instead of n yolo_adamw_job_fill calls
+int yolo_adamw_jobs_set_grads(void* jobs_host, int njobs, const void* const* grads) {
+    AdamJob* jobs = (AdamJob*)jobs_host;
+    for (int i = 0; i < njobs; ++i) jobs[i].g = grads[i];
+    return YOLO_OK;
+}
+
 // assign the chunk ranges; returns the number of workgroups
 long yolo_adamw_jobs_finalize(void* jobs_host, int njobs) {
     AdamJob* jobs = (AdamJob*)jobs_host;

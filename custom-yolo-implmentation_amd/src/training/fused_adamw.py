@@ -87,6 +87,9 @@ class HipAdamW(torch.optim.Optimizer):
     # ------------------------------------------------------------------------------------------ step
     @torch.no_grad()
     def step(self, closure=None):
+        """One launch for all parameters of a group.  Deviation from torch.optim.AdamW: the step counter (bias correction)
+        is per GROUP, not per parameter -- a parameter that receives no gradient on some steps is corrected as if it had
+        been stepped with the others (the reference's model gives every parameter a gradient on every step)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -101,7 +104,30 @@ class HipAdamW(torch.optim.Optimizer):
             capturing = torch.cuda.is_current_stream_capturing()
             ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
             if plan["ptrs"] != ptrs:
-                self._build(plan, params, capturing)
+                old = plan["ptrs"]
+                if (not capturing and old is not None and len(old) == len(ptrs) and plan["host"] is not None
+                        and all(a[0] == b[0] and a[2] == b[2] for a, b in zip(old, ptrs))
+                        and plan.get("gdtypes") == tuple(p.grad.dtype for p in params)):
+                    # same parameters, fresh gradient tensors (an eager loop's zero_grad(set_to_none=True)): one call
+                    # rewrites the gradient pointers instead of a job_fill call per parameter
+                    # The upload is asynchronous from one of TWO pinned staging tables; a table is rewritten only after
+                    # the upload that last read it has completed (its event): no host sync unless the device is two
+                    # steps behind.
+                    import ctypes
+                    stage = plan.setdefault("stage", [plan["host"].clone().pin_memory(), plan["host"].clone().pin_memory()])
+                    evs = plan.setdefault("stage_ev", [None, None])
+                    k = plan["stage_k"] = 1 - plan.get("stage_k", 1)
+                    if evs[k] is not None:
+                        evs[k].synchronize()
+                    stage[k].copy_(plan["host"])
+                    arr = (ctypes.c_void_p * len(ptrs))(*[t[1] for t in ptrs])
+                    lib.call("yolo_adamw_jobs_set_grads", stage[k].data_ptr(), len(ptrs), arr)
+                    plan["jobs_dev"].copy_(stage[k], non_blocking=True)
+                    evs[k] = torch.cuda.Event()
+                    evs[k].record()
+                else:
+                    self._build(plan, params, capturing)
+                    plan["gdtypes"] = tuple(p.grad.dtype for p in params)
                 plan["ptrs"] = ptrs
             if not capturing:
                 self.sync_hyper()

@@ -66,6 +66,7 @@ int yolo_pack_batched(const void* jobs_dev, int njobs, long nchunks, int out_dty
 int yolo_adamw_job_bytes();
 int yolo_adamw_job_fill(void* jobs_host, int index, void* p, int p_dtype, const void* g, int g_dtype, float* m, float* v, long n);
 long yolo_adamw_jobs_finalize(void* jobs_host, int njobs);
+int yolo_adamw_jobs_set_grads(void* jobs_host, int njobs, const void* const* grads);
 int yolo_adamw_step(const void* jobs_dev, int njobs, long nchunks, const double* hyper, float* step, const float* grad_scale, const float* found_inf, hipStream_t st);
 /* ---- gradient exchange: pack / unpack every parameter gradient into / out of the flat communication buffers in one launch
    (DistributedDataParallel's bucket copies: src/training/utils_train.py:190); jobs: device copy of a host table of
