@@ -20,6 +20,9 @@
 #include "conv_dev.h"
 
 int halo_conv_eligible(const ConvGeom& g);
+int rows_conv_eligible(const ConvGeom& g);
+int rows_conv_launch(const ConvGeom& g, int variant, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
+                     int dtype, hipStream_t st);
 int halo_conv_launch(const ConvGeom& g, int variant, const void* src, const void* wm, const float* bias, void* dst,
                      int accumulate, int dtype, hipStream_t st);
 
@@ -522,7 +525,7 @@ int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void
 static int halo_variant(const ConvGeom& g) {
     const int v = conv_tune().halo;
     if (!halo_conv_eligible(g)) return 0;
-    if (v >= 0) return v > 4 ? 0 : v;
+    if (v >= 0 && v <= 4) return v;                          // 5..7 steer the row-block kernel only
     // measured in the training step (preset s, 32 images): the halo kernel wins on maps of 80x80 and more
     // (16x16-pixel tiles: 63 vs 81 us for 128->64 @80x80) and on 40x40 with exactly two 64-channel wave columns;
     // on smaller maps / other widths its tiles are too few or half empty and the gather kernel is level or better
@@ -531,8 +534,25 @@ static int halo_variant(const ConvGeom& g) {
     return 0;
 }
 
+// Maps 20 or 40 pixels wide: the row-block kernel (conv_rows.hip).  Returns 0 (not taken) or its variant (1 = 64-channel
+// workgroup tile / four weight stages, 2 = 128-channel / three, 3 = 64-channel / three).  yolo_conv_tune_set's third
+// field: 5 = take it wherever eligible, 6 / 7 / 8 = force variant 1 / 2 / 3, 0..4 = never.
+// Default (tools/rows_bench.py, graph-replayed, 32 images): every 20-wide layer (128->128: 17.8 -> 12.6 us forward,
+// 16.2 -> 11.7 data gradient; 512->64 forward 42.5 -> 24.2) and the 40-wide ones with 64 destination channels and a deeper
+// source (256->64 forward 38.2 -> 30.8); the other 40-wide shapes are level or up to 20 % ahead on the gather ring.
+static int rows_variant(const ConvGeom& g) {
+    const int v = conv_tune().halo;
+    if (!rows_conv_eligible(g)) return 0;
+    if ((v >= 0 && v < 5) || v == 9) return 0;               // 9: this kernel off, everything else automatic (A/B runs)
+    if (v == 6) return 1;
+    if (v == 7) return g.Cd > 64 ? 2 : 1;
+    if (v == 8 || v == 5) return 3;
+    return (g.Wg == 20 || (g.Cd == 64 && g.Cs >= 128)) ? 3 : 0;
+}
+
 int mfma_conv_plan(const ConvGeom& g, int dtype) {
     static const long long dummy[2] = {0, 0};
+    if (const int rv = rows_variant(g)) return 4000 + rv;
     if (const int hv = halo_variant(g)) return 2000 + hv;
     if (ring_conv_eligible(g, dtype, dummy, dummy, dummy)) return ring_conv_plan(&g, 1);
     return 1000 + conv_tile_bn(to_dev(g));
@@ -541,6 +561,7 @@ int mfma_conv_plan(const ConvGeom& g, int dtype) {
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                      int dtype, hipStream_t st) {
     if ((long)g.N * g.Hg * g.Wg == 0) return YOLO_OK;
+    if (const int rv = rows_variant(g)) return rows_conv_launch(g, rv, src, wm, bias, dst, accumulate, dtype, st);
     if (const int hv = halo_variant(g)) return halo_conv_launch(g, hv, src, wm, bias, dst, accumulate, dtype, st);
     if (ring_conv_eligible(g, dtype, src, wm, dst)) {
         const long off0 = 0;
