@@ -11,6 +11,9 @@ int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void
 int mfma_conv_plan(const ConvGeom& g, int dtype);
 int ring_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst);
 int ring_conv_plan(const ConvGeom* gs, int n);
+int up2_conv_variant(const ConvGeom* gs, int dtype);
+int up2_conv_launch(const ConvGeom* gs, int variant, const long* wm_off, long wm_elems, const void* src, const void* wm, void* dst,
+                    int accumulate, int dtype, hipStream_t st);
 int ring_conv_launch(const ConvGeom* gs, int n, const long* wm_off, long wm_elems, const void* src, const void* wm,
                      const float* bias, void* dst, int accumulate, int dtype, hipStream_t st);
 int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const float* bias, void* dst,
@@ -472,6 +475,8 @@ static int conv2d_dgrad_impl(const void* dy, int lddy, const void* wb, void* dx,
         ring = ring && ring_conv_eligible(gs[c], dtype, dy, wb, dx);
         off += (long)Cin * gs[c].Kpad;
     }
+    if (algo != 1 && stride == 2)                             // large maps: the dy patch once for all four classes (conv_up2.hip)
+        if (const int uv = up2_conv_variant(gs, dtype)) return up2_conv_launch(gs, uv, offs, off, dy, wb, dx, accumulate, dtype, st);
     if (ring)                                                 // one launch for the four parity classes
         return ring_conv_launch(gs, 4, offs, off, dy, wb, nullptr, dx, accumulate, dtype, st);
     for (int c = 0; c < ncls; ++c) {
@@ -498,6 +503,7 @@ int yolo_conv2d_plan(int N, int H, int W, int Cin, int OH, int OW, int Cout, int
             gs[c] = dgrad_geom(Cout, Cin, N, H, W, Cin, OH, OW, Cout, k, stride, c);
             all = all && ring_conv_eligible(gs[c], dtype, dummy, dummy, dummy);
         }
+        if (const int uv = up2_conv_variant(gs, dtype)) return 5000 + uv;
         if (all) return ring_conv_plan(gs, 4);
     }
     return mfma_conv_plan(g, dtype);

@@ -8,8 +8,8 @@
 //     pixel order -- a tile may wrap from one row into the next, a lane's pixel only fixes its offset into the staged
 //     patch and the taps stay nine scalar offsets;
 //   * per 32-channel chunk the (rows + 2) x (W + 2) halo patch is staged ONCE, by LDS-DMA, two chunks deep (64-byte
-//     pixel rows, the four 16-byte chunks XOR-swizzled by (pixel >> 2) & 3: any 16 consecutive patch pixels hit 16
-//     different bank groups);
+//     pixel rows, the four 16-byte chunks XOR-swizzled by (pixel >> 1) & 3, patch rows W + 8 pixels apart: conflict-free for ds_read_b128's
+//     lane groups at any pixel offset, also where a tile wraps into the next row);
 //   * the four waves split the OUTPUT CHANNELS (16 or 32 each) and share the five pixel tiles, so the weight tile of a
 //     step -- one kernel row = three taps x BN x 32 -- is the only per-step traffic; it runs through a ring of NST stages
 //     filled by LDS-DMA and retired by counted s_waitcnt (the idiom of conv_ring.hip): NST-1 steps of weights plus the
@@ -30,7 +30,7 @@ template <typename T, int W, int NWAVE, int WN, int NST, bool ACC>
 __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
                                                    const float* __restrict__ bias, T* __restrict__ dst, int tiles_h,
                                                    int ntile_n) {
-    constexpr int R = 80 / W, HWID = W + 2, HH = R + 2, HPX = HH * HWID;
+    constexpr int R = 80 / W, HWID = W + 8, HH = R + 2, HPX = HH * HWID;     // row pitch W + 8: a tile that wraps into the next row keeps the bank pattern
     constexpr int NTHR = 64 * NWAVE, BN = NWAVE * WN * 16;
     constexpr int HP = 12 / NWAVE;                           // patch pieces (16 pixels x 64 bytes) per wave: 12 x 16 >= HPX
     constexpr int DW = 3 * WN;                               // weight pieces (16 rows x 64 bytes) per wave and step: 3 taps x BN rows
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     int hvoff[HP], wvoff[DW];
 #pragma unroll
     for (int i = 0; i < HP; ++i) {
-        const int px = (wave * HP + i) * 16 + (lane >> 2), ck = (lane & 3) ^ ((px >> 2) & 3);
+        const int px = (wave * HP + i) * 16 + (lane >> 2), ck = (lane & 3) ^ ((px >> 1) & 3);
         const int hy = px / HWID, hx = px - hy * HWID;
         const bool ok = px < HPX && (unsigned)(y0 - 1 + hy) < (unsigned)g.Hs && (unsigned)(hx - 1) < (unsigned)g.Ws;
         hvoff[i] = ok ? ((hy * g.Ws + hx) * g.lds + ck * 8) * 2 : OOB;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int px = apx[i] + toff;
-                fb[i] = *reinterpret_cast<const frag*>(hp + px * 64 + ((fg ^ ((px >> 2) & 3)) << 4));
+                fb[i] = *reinterpret_cast<const frag*>(hp + px * 64 + ((fg ^ ((px >> 1) & 3)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i)

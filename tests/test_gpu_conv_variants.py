@@ -301,15 +301,26 @@ def test_config2_weight_gradient_calls_elementwise(config2_calls):
     assert not failures, "\n".join(failures)
 
 
+@pytest.mark.parametrize("cin,cout,variant", [(32, 64, 16), (72, 96, 8), (128, 32, 8), (40, 64, 8)])
+def test_stride2_dgrad_patch_kernel(cin, cout, variant):
+    """conv_up2.hip: all four parity classes from one staged dy patch; dy grid 42 x 50 (no multiple of the 8- / 16-row and
+    16-column tiles), dx channel counts that do not fill the last 64-channel tile, channel slices of wider buffers,
+    accumulate on and off"""
+    q = lib().query
+    got = [q("yolo_conv2d_plan", 3, 84, 100, cin, 42, 50, cout, 3, 2, 1, c, lib().BF16) for c in range(4)]
+    assert all(g == 5000 + variant for g in got), got
+    run_fwd_dgrad_case(3, cin, cout, 84, 100, 3, 2, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, stats=False, seed=cin + cout)
+
+
 def test_stride2_dgrad_real_shape_all_parity_classes():
     """128 -> 128 3x3 stride 2 on a 160 x 160 map, 32 images (the biggest conv of preset s): four parity-class launches."""
     q = lib().query
     got = [q("yolo_conv2d_plan", 32, 160, 160, 128, 80, 80, 128, 3, 2, 1, c, lib().BF16) for c in range(4)]
-    assert all(g // 1000 in (1, 3) for g in got), got       # an MFMA kernel (gather, per class / ring, one launch)
+    assert all(g == 5008 for g in got), got                 # conv_up2.hip: the dy patch once for all four classes
     run_fwd_dgrad_case(32, 128, 128, 160, 160, 3, 2, images=[0, 17, 31], stats=True, acc=(False, True), seed=77)
-    # the same layer on a 40 x 40 map: the four classes go out as ONE ring launch
+    # the same layer on a 40 x 40 map (dy grid 20 x 20: partial tiles in both directions)
     got = [q("yolo_conv2d_plan", 32, 40, 40, 256, 20, 20, 256, 3, 2, 1, c, lib().BF16) for c in range(4)]
-    assert all(g // 1000 == 3 for g in got), got
+    assert all(g == 5008 for g in got), got
     run_fwd_dgrad_case(32, 256, 256, 40, 40, 3, 2, images=[0, 17, 31], stats=True, acc=(False, True), seed=79)
     # odd map: the parity classes have different sizes
     run_fwd_dgrad_case(2, 64, 64, 45, 39, 3, 2, images=[0, 1], stats=False, seed=78)
