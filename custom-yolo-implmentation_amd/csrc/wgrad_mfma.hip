@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
                                                 float* __restrict__ dwp) {
     constexpr int PAD = KS / 2;
     constexpr int PH = 3 * S + KS, PW = 7 * S + KS;          // X patch (with halo) for 4 x 8 outputs
-    constexpr int LDY = ldc_of(TCO), LDX = ldc_of(TCI);
+    // stride 2 spreads the four patch columns of a transposing read two pixels apart: 32- and 96-channel rows then put them
+    // on the same banks four ways (SQ_LDS_BANK_CONFLICT), 8 elements of padding bring it back to the two-way floor of this mapping
+    constexpr int LDY = ldc_of(TCO), LDX = ldc_of(TCI) + ((S == 2 && (TCI & 1)) ? 8 : 0);
     constexpr int CPY = TCO * 4, CPX = TCI * 4;               // 16-byte chunks per pixel (dY / X tile)
     constexpr int YCH = 32 * CPY, YR = (YCH + 255) / 256;     // dY chunks per patch / per thread
     constexpr int XCH = PH * PW * CPX;                        // 16-byte chunks in the X patch

@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC counters of one kernel: pmc_kernel.sh OUTDIR KERNEL_SUBSTRING -- program args...   (counter passes run separately)
+# PMC counters summed per kernel-name substring: pmc_kernel.sh OUTDIR SUBSTR[,SUBSTR...] -- program args...
+# (six counter sets, each in its own rocprofv3 --kernel-trace --pmc pass)
 out=$1; pat=$2; shift 3
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -10,13 +11,15 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_IN
   python3 - "$out/p$i/c_counter_collection.csv" "$pat" <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(float); n = collections.Counter()
+pats = sys.argv[2].split(",")
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        if sys.argv[2] in r["Kernel_Name"]:
-            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+        for p in pats:
+            if p in r["Kernel_Name"]:
+                acc[p, r["Counter_Name"]] += float(r["Counter_Value"]); n[p, r["Counter_Name"]] += 1
 except Exception as e:
     print("no csv:", e)
-for k in acc: print(f"{k:32s} {acc[k] / max(n[k],1):16.0f}  per launch ({n[k]} launches)")
+for (p, k) in sorted(acc): print(f"{p:24s} {k:32s} {acc[p, k]:16.0f} total over {n[p, k]} launches")
 PY
   rm -rf $out/p$i
 done
