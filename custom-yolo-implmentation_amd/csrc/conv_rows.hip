@@ -94,12 +94,19 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     const int crow = wave * WN * 16;
     const int fr = lane & 15, fg = lane >> 4;
     const int fk = (fg ^ ((-(fr >> 2)) & 3)) * 16;           // byte offset of this lane's swizzled weight chunk
-    int apx[5];                                              // patch pixel of this lane's pixel of tile i at tap (0, 0)
+    // swizzled byte offset of this lane's fragment of (pixel tile i, tap) inside a patch buffer: 45 registers instead of five
+    // address instructions per read (PMC: 5.7 VALU per MFMA before, and one wave per SIMD issues them in line with its MFMAs)
+    int aoff[5][9];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int p = i * 16 + fr, pr = p / W, pc = p - pr * W;
-        apx[i] = (pr + 1) * HWID + pc + 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int px = (pr + (int)((g.dh_pack >> (2 * tap)) & 3u)) * HWID + pc + (int)((g.dw_pack >> (2 * tap)) & 3u);
+            aoff[i][tap] = px * 64 + ((fg ^ ((px >> 1) & 3)) << 4);
+        }
     }
+    const int woff = (crow + fr) * 64 + fk;                  // this lane's byte offset inside a 16-row weight block
     f32x4 acc[5][WN];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -110,28 +117,25 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue_w();
     int rbuf = 0;
-    auto step = [&](auto srow_c, int chunk) {
-        constexpr int srow = decltype(srow_c)::value;
+    auto step = [&](auto srow_c, auto par_c, int chunk) {
+        constexpr int srow = decltype(srow_c)::value, par = decltype(par_c)::value;   // par: patch buffer of this chunk (static: folds into the read's immediate)
         // newer than this step's weights: NST-2 later steps, and the next patch when it went out in one of those iterations
         constexpr bool patch_newer = srow != 0 && (NST == 4 || srow == 1);
         rows_wait<(NST - 2) * DW + (patch_newer ? HP : 0)>();
         __builtin_amdgcn_s_barrier();                        // everyone's pieces of this step are in; the stage / patch read last step is free
         if (srow == 0) issue_halo(chunk + 1);
         issue_w();
-        const char* hp = rows_smem + (chunk & 1) * HBUF;
-        const char* wp = rows_smem + 2 * HBUF + rbuf * STAGE;
+        const char* hp = rows_smem + par * HBUF;
+        // three stages, three steps per chunk: the ring slot of a step is its kernel row -- static as well
+        const char* wp = rows_smem + 2 * HBUF + (NST == 3 ? srow : rbuf) * STAGE;
 #pragma unroll
         for (int tl = 0; tl < 3; ++tl) {
             const int tap = 3 * srow + tl;
-            const int toff = ((int)((g.dh_pack >> (2 * tap)) & 3u) - 1) * HWID + ((int)((g.dw_pack >> (2 * tap)) & 3u) - 1);
             frag fa[WN], fb[5];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) fa[j] = *reinterpret_cast<const frag*>(wp + (tl * BN + crow + j * 16 + fr) * 64 + fk);
+            for (int j = 0; j < WN; ++j) fa[j] = *reinterpret_cast<const frag*>(wp + (tl * BN + j * 16) * 64 + woff);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int px = apx[i] + toff;
-                fb[i] = *reinterpret_cast<const frag*>(hp + px * 64 + ((fg ^ ((px >> 1) & 3)) << 4));
-            }
+            for (int i = 0; i < 5; ++i) fb[i] = *reinterpret_cast<const frag*>(hp + aoff[i][tap]);
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -139,11 +143,15 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
         }
         if (++rbuf == NST) rbuf = 0;
     };
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        step(std::integral_constant<int, 0>{}, chunk);
-        step(std::integral_constant<int, 1>{}, chunk);
-        step(std::integral_constant<int, 2>{}, chunk);
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    int chunk = 0;
+    for (; chunk + 1 < nchunk; chunk += 2) {
+        step(c0{}, c0{}, chunk); step(c1{}, c0{}, chunk); step(c2{}, c0{}, chunk);
+        step(c0{}, c1{}, chunk + 1); step(c1{}, c1{}, chunk + 1); step(c2{}, c1{}, chunk + 1);
     }
+    if (chunk < nchunk) { step(c0{}, c0{}, chunk); step(c1{}, c0{}, chunk); step(c2{}, c0{}, chunk); }
     rows_wait<0>();                                          // the zero-fill pieces issued past the end of K
     __syncthreads();
     T* const wl = reinterpret_cast<T*>(rows_smem);           // LDS is idle from here on (statistics scratch)

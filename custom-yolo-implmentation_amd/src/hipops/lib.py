@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- must come first: libyolo_hip.so has to bind to th
 #                       or its launches would go through a second runtime that does not know torch's streams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libyolo_hip.so")
+SO_PATH = os.environ.get("YOLO_HIP_SO_TMP") or os.path.join(_HERE, "libyolo_hip.so")
 HEADER_PATHS = [os.path.join(_HERE, "..", "..", "..", "include", "yolo_hip.h"),
                 os.path.join(_HERE, "yolo_hip.h")]
 
