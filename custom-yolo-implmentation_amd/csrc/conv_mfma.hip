@@ -534,20 +534,23 @@ static int halo_variant(const ConvGeom& g) {
     return 0;
 }
 
-// Maps 20 or 40 pixels wide: the row-block kernel (conv_rows.hip).  Returns 0 (not taken) or its variant (1 = 64-channel
-// workgroup tile / four weight stages, 2 = 128-channel / three, 3 = 64-channel / three).  yolo_conv_tune_set's third
-// field: 5 = take it wherever eligible, 6 / 7 / 8 = force variant 1 / 2 / 3, 0..4 = never.
-// Default (tools/rows_bench.py, graph-replayed, 32 images): every 20-wide layer (128->128: 17.8 -> 12.6 us forward,
-// 16.2 -> 11.7 data gradient; 512->64 forward 42.5 -> 24.2) and the 40-wide ones with 64 destination channels and a deeper
-// source (256->64 forward 38.2 -> 30.8); the other 40-wide shapes are level or up to 20 % ahead on the gather ring.
+// Maps 20 or 40 pixels wide: the row-block kernel (conv_rows.hip).  Returns 0 (not taken) or its variant (1 / 3 = 80 pixels
+// x 64 channels per workgroup with four / three weight stages, 2 = 80 x 128, 4 = 160 x 64).  yolo_conv_tune_set's third
+// field: 5 = default choice wherever eligible, 6 / 7 / 8 / 12 = force variant 1 / 2 / 3 / 4, 0..4 and 9 = never.
+// Default (tools/rows_bench.py, graph-replayed, 32 images, against the gather ring): 40-wide maps take the 160 x 64 tile
+// (256->256: 83 -> 63 us, 64->64: 15.0 -> 12.8, 256->64: 38 -> 25), 20-wide maps too once the 80 x 64 tiling would put two
+// workgroups on every CU (256->256: 35 -> 24 us), otherwise 80 x 64 (128->128: 17.8 -> 11.7, 512->64: 42.6 -> 21.5).
 static int rows_variant(const ConvGeom& g) {
     const int v = conv_tune().halo;
     if (!rows_conv_eligible(g)) return 0;
     if ((v >= 0 && v < 5) || v == 9) return 0;               // 9: this kernel off, everything else automatic (A/B runs)
     if (v == 6) return 1;
     if (v == 7) return g.Cd > 64 ? 2 : 1;
-    if (v == 8 || v == 5) return 3;
-    return (g.Wg == 20 || (g.Cd == 64 && g.Cs >= 128)) ? 3 : 0;
+    if (v == 8) return 3;
+    if (v == 12) return 4;
+    if (g.Wg == 40) return 4;
+    const long wgs = (long)g.N * ((g.Hg + 3) / 4) * ((g.Cd + 63) / 64);
+    return wgs >= 512 ? 4 : 3;
 }
 
 int mfma_conv_plan(const ConvGeom& g, int dtype) {

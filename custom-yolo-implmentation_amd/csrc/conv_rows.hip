@@ -26,17 +26,18 @@ __device__ __forceinline__ void rows_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds
 }
 template <int N> __device__ __forceinline__ void rows_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <typename T, int W, int NWAVE, int WN, int NST, bool ACC>
+template <typename T, int W, int WGM, int NWAVE, int WN, int NST, bool ACC>
 __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
                                                    const float* __restrict__ bias, T* __restrict__ dst, int tiles_h,
                                                    int ntile_n) {
-    constexpr int R = 80 / W, HWID = W + 8, HH = R + 2, HPX = HH * HWID;     // row pitch W + 8: a tile that wraps into the next row keeps the bank pattern
-    constexpr int NTHR = 64 * NWAVE, BN = NWAVE * WN * 16;
-    constexpr int HP = 12 / NWAVE;                           // patch pieces (16 pixels x 64 bytes) per wave: 12 x 16 >= HPX
-    constexpr int DW = 3 * WN;                               // weight pieces (16 rows x 64 bytes) per wave and step: 3 taps x BN rows
-    constexpr int HBUF = 12 * 1024, STAGE = 3 * BN * 64;     // bytes: one patch buffer, one weight stage
+    constexpr int R = WGM * 80 / W, HWID = W + 8, HH = R + 2, HPX = HH * HWID;     // row pitch W + 8: a tile that wraps into the next row keeps the bank pattern
+    constexpr int WGN = NWAVE / WGM;                         // waves: WGM groups of five pixel tiles x WGN channel groups
+    constexpr int NTHR = 64 * NWAVE, BN = WGN * WN * 16;
+    constexpr int HP = ((HPX + 15) / 16 + NWAVE - 1) / NWAVE; // patch pieces (16 pixels x 64 bytes) per wave
+    constexpr int DW = 3 * BN / 16 / NWAVE;                  // weight pieces (16 rows x 64 bytes) per wave and step: 3 taps x BN rows
+    constexpr int HBUF = NWAVE * HP * 1024, STAGE = 3 * BN * 64;     // bytes: one patch buffer, one weight stage
     constexpr int OOB = (int)0x80000000;
-    static_assert(R * W == 80 && HPX <= 12 * 16 && NST >= 3 && NST <= 4 && (NWAVE == 2 || NWAVE == 4), "block shape");
+    static_assert(R * W == WGM * 80 && NST >= 3 && NST <= 4 && NWAVE == 4 && (3 * BN / 16) % NWAVE == 0, "block shape");
     using ops = mfma_ops<T>;
     using frag = typename ops::frag;
     extern __shared__ __attribute__((aligned(1024))) char rows_smem[];        // [2][HBUF] patches, [NST][STAGE] weights
@@ -90,8 +91,9 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
         if (++wbuf == NST) wbuf = 0;
     };
 
-    // ---- compute state: every wave works on the block's five pixel tiles; wave w owns channels w*WN*16 .. +WN*16
-    const int crow = wave * WN * 16;
+    // ---- compute state: wave (wgm, wgn) works on pixel tiles wgm*5 .. +4 and owns channels wgn*WN*16 .. +WN*16
+    const int wgm = wave / WGN, wgn = wave - wgm * WGN;
+    const int crow = wgn * WN * 16;
     const int fr = lane & 15, fg = lane >> 4;
     const int fk = (fg ^ ((-(fr >> 2)) & 3)) * 16;           // byte offset of this lane's swizzled weight chunk
     // swizzled byte offset of this lane's fragment of (pixel tile i, tap) inside a patch buffer: 45 registers instead of five
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     int aoff[5][9];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const int p = i * 16 + fr, pr = p / W, pc = p - pr * W;
+        const int p = (wgm * 5 + i) * 16 + fr, pr = p / W, pc = p - pr * W;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int px = (pr + (int)((g.dh_pack >> (2 * tap)) & 3u)) * HWID + pc + (int)((g.dw_pack >> (2 * tap)) & 3u);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const int p = i * 16 + fr, pr = p / W, pc = p - pr * W;
+        const int p = (wgm * 5 + i) * 16 + fr, pr = p / W, pc = p - pr * W;
         const int oy = y0 + pr;
         if (oy < g.Hg) {
             const long pix = ((long)n * g.Hd + oy) * (long)g.Wd + pc;
@@ -240,21 +242,21 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     }
 }
 
-template <typename T, int W, int NWAVE, int WN, int NST>
+template <typename T, int W, int WGM, int NWAVE, int WN, int NST>
 int launch_rows(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate, hipStream_t st) {
-    constexpr int R = 80 / W, BN = NWAVE * WN * 16;
-    constexpr size_t lds = 2 * 12 * 1024 + (size_t)NST * 3 * BN * 64;
+    constexpr int R = WGM * 80 / W, BN = (NWAVE / WGM) * WN * 16, HPX = (R + 2) * (W + 8);
+    constexpr size_t lds = 2 * (size_t)(NWAVE * (((HPX + 15) / 16 + NWAVE - 1) / NWAVE)) * 1024 + (size_t)NST * 3 * BN * 64;
     const int th = (d.Hg + R - 1) / R, tn = (d.Cd + BN - 1) / BN;
     const dim3 grid((unsigned)(d.N * th * tn));
     hipError_t e;
     if (accumulate) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, NWAVE, WN, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_conv_rows<T, W, NWAVE, WN, NST, true>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tn);
+        hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tn);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, NWAVE, WN, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_conv_rows<T, W, NWAVE, WN, NST, false>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tn);
+        hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tn);
     }
     return YOLO_LAUNCH_CHECK();
 }
@@ -275,14 +277,19 @@ int rows_conv_eligible(const ConvGeom& g) {
 int rows_conv_launch(const ConvGeom& g, int variant, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
                      int dtype, hipStream_t st) {
     const GeomDev d = to_dev(g);
-    // variant: 1 = 16 channels per wave, four weight stages; 2 = 32 per wave, three; 3 = 16 per wave, three.  (Two-wave
-    // workgroups with 32 / 64 channels per wave -- fewer LDS reads per MFMA -- measured 15-40 % slower: one wave per SIMD
-    // cannot hide its own ds_read -> MFMA latency.)
+    // variant: 80 pixels x 64 channels, 16 channels per wave: 1 = four weight stages, 3 = three; 2 = 80 x 128 (32 per wave);
+    // 4 = 160 pixels x 64 channels: two pixel groups x two channel groups of waves, wave tile 5 x 2.
+    // Measured with the compute or the DMA compiled out (256->256 @40x40, 80 x 64 tile, 87 us): DMA ring + barriers alone 64 us
+    // (60 GB/s per CU through the L2 -> LDS fill path, three quarters of it weights), fragment reads + MFMAs + barriers alone
+    // 63 us -- both sides bound it.  Twice the pixels per workgroup halves the weight fill per output AND the LDS reads per
+    // MFMA (0.7 instead of 1.2): 62 us, and every 40-wide layer gains; 160 x 128 (one workgroup per CU) and two-wave
+    // workgroups lose again.
 #define ROWS_W(T_, W_)                                                                                               \
     switch (variant) {                                                                                               \
-        case 2: return launch_rows<T_, W_, 4, 2, 3>(d, src, wm, bias, dst, accumulate, st);                          \
-        case 3: return launch_rows<T_, W_, 4, 1, 3>(d, src, wm, bias, dst, accumulate, st);                          \
-        default: return launch_rows<T_, W_, 4, 1, 4>(d, src, wm, bias, dst, accumulate, st);                         \
+        case 2: return launch_rows<T_, W_, 1, 4, 2, 3>(d, src, wm, bias, dst, accumulate, st);                          \
+        case 3: return launch_rows<T_, W_, 1, 4, 1, 3>(d, src, wm, bias, dst, accumulate, st);                       \
+        case 4: return launch_rows<T_, W_, 2, 4, 2, 3>(d, src, wm, bias, dst, accumulate, st);                       \
+        default: return launch_rows<T_, W_, 1, 4, 1, 4>(d, src, wm, bias, dst, accumulate, st);                         \
     }
 #define ROWS_T(T_)                                                                                                   \
     if (g.Wg == 20) { ROWS_W(T_, 20) }                                                                               \

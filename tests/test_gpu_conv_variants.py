@@ -178,14 +178,14 @@ def test_halo_kernel_every_variant(variant, cin, cout):
                        seed=variant)
 
 
-@pytest.mark.parametrize("force", [6, 7, 8])
+@pytest.mark.parametrize("force", [6, 7, 8, 12])
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 23, 20), (32, 64, 13, 40), (96, 200, 9, 20), (128, 72, 20, 40)])
 def test_rows_kernel_both_tiles_on_narrow_maps(force, cin, cout, h, w):
     """conv_rows.hip: 20- and 40-pixel-wide maps whose height is no multiple of the 4- / 2-row block, channel counts
     that do not fill the last channel tile"""
     lib().call("yolo_conv_tune_set", 0, -1, force, -1, -1, 0, 0, 0)
     run_fwd_dgrad_case(3, cin, cout, h, w, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16,
-                       want_plan=4000 + {6: 1, 7: 2 if cout > 64 else 1, 8: 3}[force], seed=force)
+                       want_plan=4000 + {6: 1, 7: 2 if cout > 64 else 1, 8: 3, 12: 4}[force], seed=force)
 
 
 @pytest.mark.parametrize("to,ti", [(1, 1), (1, 2), (2, 1), (2, 2)])

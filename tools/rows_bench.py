@@ -24,8 +24,8 @@ for (n, cin, h, w, cout) in shapes:
     y = torch.empty_like(dy)
     for name, fn in (("fwd", lambda: ops.conv_fwd(x, wp, None, cout, 3, 1, acc, out=y)), ("dgrad", lambda: ops.conv_dgrad(dy, wb, cin, h, w, 3, 1))):
         res = []
-        for hv in (0, 6, 7, 8):
+        for hv in (0, 8, 12, -1):
             tune(0, -1, hv)
             res.append(timeit(fn))
         tune()
-        print(f"{name:5s} {cin:4d}->{cout:4d} {h}x{w}  gather ring {res[0]:6.1f} us  rows64 {res[1]:6.1f}  rows128 {res[2]:6.1f}  rows64n3 {res[3]:6.1f}", flush=True)
+        print(f"{name:5s} {cin:4d}->{cout:4d} {h}x{w}  gather ring {res[0]:6.1f} us  80px x 64 {res[1]:6.1f}  160px x 64 {res[2]:6.1f}  default {res[3]:6.1f}", flush=True)
