@@ -536,14 +536,20 @@ static int halo_variant(const ConvGeom& g) {
 
 // Maps 20 or 40 pixels wide: the row-block kernel (conv_rows.hip).  Returns 0 (not taken) or its variant (1 / 3 = 80 pixels
 // x 64 channels per workgroup with four / three weight stages, 2 = 80 x 128, 4 = 160 x 64).  yolo_conv_tune_set's third
-// field: 5 = default choice wherever eligible, 6 / 7 / 8 / 12 = force variant 1 / 2 / 3 / 4, 0..4 and 9 = never.
+// field: 5 = default choice wherever eligible, 6 / 7 / 8 / 12 = force variant 1 / 2 / 3 / 4, 14 = variant 6 (10 rows of a
+// 16-pixel-wide block x 64 channels, maps of any width), 0..4 and 9 = never.
 // Default (tools/rows_bench.py, graph-replayed, 32 images, against the gather ring): 40-wide maps take the 160 x 64 tile
 // (256->256: 83 -> 63 us, 64->64: 15.0 -> 12.8, 256->64: 38 -> 25), 20-wide maps too once the 80 x 64 tiling would put two
 // workgroups on every CU (256->256: 35 -> 24 us), otherwise 80 x 64 (128->128: 17.8 -> 11.7, 512->64: 42.6 -> 21.5).
 static int rows_variant(const ConvGeom& g) {
     const int v = conv_tune().halo;
-    if (!rows_conv_eligible(g)) return 0;
+    const int el = rows_conv_eligible(g);
+    if (!el) return 0;
     if ((v >= 0 && v < 5) || v == 9) return 0;               // 9: this kernel off, everything else automatic (A/B runs)
+    if (v == 14) return 6;                                   // 16-pixel-wide blocks, any map width
+    // wider maps: 10 x 16-pixel blocks x 64 channels beat the halo kernel where the layer has exactly one 64-channel tile
+    // (64->64 @80x80 35 -> 31 us forward, 31.5 -> 26.8 data gradient; 128->64 forward 51.5 -> 41.5; 64->64 @160x160 104 -> 97)
+    if (el != 1) return (v < 0 || v == 5) && g.Cd == 64 && g.Cs >= 64 ? 6 : 0;          // 15: full-row blocks only (A/B)
     if (v == 6) return 1;
     if (v == 7) return g.Cd > 64 ? 2 : 1;
     if (v == 8) return 3;

@@ -29,8 +29,10 @@ template <int N> __device__ __forceinline__ void rows_wait() { asm volatile("s_w
 template <typename T, int W, int WGM, int NWAVE, int WN, int NST, bool ACC>
 __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,
                                                    const float* __restrict__ bias, T* __restrict__ dst, int tiles_h,
-                                                   int ntile_n) {
-    constexpr int R = WGM * 80 / W, HWID = W + 8, HH = R + 2, HPX = HH * HWID;     // row pitch W + 8: a tile that wraps into the next row keeps the bank pattern
+                                                   int tiles_w, int ntile_n) {
+    // W == 16: blocks of 16-pixel rows at column x0 of a map of any width (a pixel tile is one block row, never wraps: pitch 18);
+    // otherwise the block rows ARE map rows (tiles_w == 1, x0 == 0)
+    constexpr int R = WGM * 80 / W, HWID = W == 16 ? 18 : W + 8, HH = R + 2, HPX = HH * HWID;     // row pitch W + 8: a tile that wraps into the next row keeps the bank pattern
     constexpr int WGN = NWAVE / WGM;                         // waves: WGM groups of five pixel tiles x WGN channel groups
     constexpr int NTHR = 64 * NWAVE, BN = WGN * WN * 16;
     constexpr int HP = ((HPX + 15) / 16 + NWAVE - 1) / NWAVE; // patch pieces (16 pixels x 64 bytes) per wave
@@ -46,8 +48,10 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = tile / ntile_n, tile_n = tile - tile_m * ntile_n;
-    const int n = tile_m / tiles_h, ty = tile_m - n * tiles_h;
-    const int y0 = ty * R;
+    const int per_img = tiles_h * tiles_w;
+    const int n = tile_m / per_img, trem = tile_m - n * per_img;
+    const int ty = trem / tiles_w, tx = trem - ty * tiles_w;
+    const int y0 = ty * R, x0 = tx * W;
     const int cd0 = tile_n * BN;
 
     // ---- DMA sources: fixed per-lane byte offsets (swizzle applied to the SOURCE chunk, the LDS image is lane-linear),
@@ -59,11 +63,11 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     for (int i = 0; i < HP; ++i) {
         const int px = (wave * HP + i) * 16 + (lane >> 2), ck = (lane & 3) ^ ((px >> 1) & 3);
         const int hy = px / HWID, hx = px - hy * HWID;
-        const bool ok = px < HPX && (unsigned)(y0 - 1 + hy) < (unsigned)g.Hs && (unsigned)(hx - 1) < (unsigned)g.Ws;
+        const bool ok = px < HPX && (unsigned)(y0 - 1 + hy) < (unsigned)g.Hs && (unsigned)(x0 + hx - 1) < (unsigned)g.Ws;
         hvoff[i] = ok ? ((hy * g.Ws + hx) * g.lds + ck * 8) * 2 : OOB;
     }
     // scalar origin of the patch: pixel (n, y0-1, -1) relative to the shifted descriptor base (never negative)
-    const int hsoff0 = (((n * g.Hs + y0 - 1) * g.Ws - 1) * g.lds + shift) * 2;
+    const int hsoff0 = (((n * g.Hs + y0 - 1) * g.Ws + x0 - 1) * g.lds + shift) * 2;
 #pragma unroll
     for (int j = 0; j < DW; ++j) {
         const int rs = (wave * DW + j) * 16 + (lane >> 2);   // row of the stage: (tap of the step, channel)
@@ -170,9 +174,9 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int p = (wgm * 5 + i) * 16 + fr, pr = p / W, pc = p - pr * W;
-        const int oy = y0 + pr;
-        if (oy < g.Hg) {
-            const long pix = ((long)n * g.Hd + oy) * (long)g.Wd + pc;
+        const int oy = y0 + pr, ox = x0 + pc;
+        if (oy < g.Hg && ox < g.Wg) {
+            const long pix = ((long)n * g.Hd + oy) * (long)g.Wd + ox;
             T* drow = dst + pix * g.ldd;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
                 store_pack<T, 4>(drow + c, v);
             }
         } else {
-            // pixels below the map must not reach the statistics
+            // pixels outside the map must not reach the statistics
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -244,19 +248,19 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
 
 template <typename T, int W, int WGM, int NWAVE, int WN, int NST>
 int launch_rows(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate, hipStream_t st) {
-    constexpr int R = WGM * 80 / W, BN = (NWAVE / WGM) * WN * 16, HPX = (R + 2) * (W + 8);
+    constexpr int R = WGM * 80 / W, BN = (NWAVE / WGM) * WN * 16, HPX = (R + 2) * (W == 16 ? 18 : W + 8);
     constexpr size_t lds = 2 * (size_t)(NWAVE * (((HPX + 15) / 16 + NWAVE - 1) / NWAVE)) * 1024 + (size_t)NST * 3 * BN * 64;
-    const int th = (d.Hg + R - 1) / R, tn = (d.Cd + BN - 1) / BN;
-    const dim3 grid((unsigned)(d.N * th * tn));
+    const int th = (d.Hg + R - 1) / R, tw = W == 16 ? (d.Wg + 15) / 16 : 1, tn = (d.Cd + BN - 1) / BN;
+    const dim3 grid((unsigned)(d.N * th * tw * tn));
     hipError_t e;
     if (accumulate) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tn);
+        hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tw, tn);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tn);
+        hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tw, tn);
     }
     return YOLO_LAUNCH_CHECK();
 }
@@ -265,13 +269,14 @@ int launch_rows(const GeomDev& d, const void* src, const void* wm, const float* 
 
 // Shapes the row-block kernel takes: the nine taps of a 3x3 conv, stride 1 in source and destination, maps exactly 20 or
 // 40 pixels wide, source channels a multiple of 32, at least 64 destination channels.
+// rows_conv_eligible: 1 = full-row blocks (20- / 40-wide maps), 2 = only the 16-pixel-wide blocks (variant 6), 0 = neither
 int rows_conv_eligible(const ConvGeom& g) {
     if (!(g.sstride == 1 && g.ostep == 1 && g.ooff_h == 0 && g.ooff_w == 0 && g.ntaps == 9 && g.Cs % 32 == 0 && g.Cd >= 64 &&
-          g.Cd % 8 == 0 && g.Hg == g.Hs && g.Wg == g.Ws && g.Hd == g.Hg && g.Wd == g.Wg && (g.Wg == 20 || g.Wg == 40)))
+          g.Cd % 8 == 0 && g.Hg == g.Hs && g.Wg == g.Ws && g.Hd == g.Hg && g.Wd == g.Wg))
         return 0;
     for (int t = 0; t < 9; ++t)
         if (g.dh[t] < -1 || g.dh[t] > 1 || g.dw[t] < -1 || g.dw[t] > 1) return 0;
-    return 1;
+    return (g.Wg == 20 || g.Wg == 40) ? 1 : 2;
 }
 
 int rows_conv_launch(const ConvGeom& g, int variant, const void* src, const void* wm, const float* bias, void* dst, int accumulate,
@@ -292,6 +297,7 @@ int rows_conv_launch(const ConvGeom& g, int variant, const void* src, const void
         default: return launch_rows<T_, W_, 1, 4, 1, 4>(d, src, wm, bias, dst, accumulate, st);                         \
     }
 #define ROWS_T(T_)                                                                                                   \
+    if (variant == 6) return launch_rows<T_, 16, 2, 4, 2, 3>(d, src, wm, bias, dst, accumulate, st);   /* 10 x 16 pixels x 64 ch */ \
     if (g.Wg == 20) { ROWS_W(T_, 20) }                                                                               \
     ROWS_W(T_, 40)
     if (dtype == YOLO_BF16) { ROWS_T(bf16_t) }

@@ -188,6 +188,13 @@ def test_rows_kernel_both_tiles_on_narrow_maps(force, cin, cout, h, w):
                        want_plan=4000 + {6: 1, 7: 2 if cout > 64 else 1, 8: 3, 12: 4}[force], seed=force)
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 136, 23, 37), (32, 64, 10, 16), (96, 64, 31, 80)])
+def test_rows_kernel_16_pixel_wide_blocks(cin, cout, h, w):
+    """conv_rows.hip with 10 x 16-pixel blocks on maps of any size: partial blocks in both directions"""
+    lib().call("yolo_conv_tune_set", 0, -1, 14, -1, -1, 0, 0, 0)
+    run_fwd_dgrad_case(3, cin, cout, h, w, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=4006, seed=cin)
+
+
 @pytest.mark.parametrize("to,ti", [(1, 1), (1, 2), (2, 1), (2, 2)])
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2)])
 def test_wgrad_3x3_every_tile(to, ti, k, s):
