@@ -3,7 +3,7 @@
 FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE is doubled for the 16-byte-per-lane access patterns (gfx950 tallies 128-B
 requests at 64 B), as the micro-architecture guide prescribes."""
 import csv, sys, collections
-GROUPS = [("conv fwd+dgrad (k_conv_mfma, k_conv_ring, k_conv_halo)", ("k_conv_mfma", "k_conv_ring", "k_conv_halo"), 2.0),
+GROUPS = [("conv fwd+dgrad (k_conv_mfma, k_conv_ring, k_conv_halo, k_conv_rows, k_dgrad2_patch)", ("k_conv_mfma", "k_conv_ring", "k_conv_halo", "k_conv_rows", "k_dgrad2_patch"), 2.0),
           ("k_bn_act_fwd_train", ("k_bn_act_fwd_train",), 2.0), ("k_channel_acc (BN backward pass 1)", ("k_channel_acc",), 2.0),
           ("k_bn_act_bwd_apply_train", ("k_bn_act_bwd_apply_train",), 2.0), ("k_wgrad2", ("k_wgrad2",), 2.0),
           ("k_wgrad_reduce", ("k_wgrad_reduce",), 2.0), ("gradient fan-in (k_add_n)", ("k_add_n",), 2.0), ("ATen (any)", ("at::native",), 2.0),

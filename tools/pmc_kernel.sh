@@ -2,8 +2,9 @@
 # PMC counters summed per kernel-name substring: pmc_kernel.sh OUTDIR SUBSTR[,SUBSTR...] -- program args...
 # (six counter sets, each in its own rocprofv3 --kernel-trace --pmc pass)
 out=$1; pat=$2; shift 3
+case $out in /*) ;; *) out=$PWD/$out ;; esac
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-$OLDPWD}
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM" "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM"; do
   i=$((i+1))

@@ -30,6 +30,21 @@ r = b["roofline"]
 chains = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "chain_breakdown.py"), os.path.join(F, "stats", "run_kernel_trace.csv"), "32"],
                         capture_output=True, text=True).stdout
 gaps = rd("gaps.txt")
+sq = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sq_table.py"), os.path.join(F, "sq.log"), "3"], capture_output=True, text=True).stdout
+open(os.path.join(P, "r2_final_sq_pmc.md"), "w").write(f"""# Round 2 (final state) — SQ counters of the step's MFMA kernel families (MI355X, preset s @640 bf16, 32 img)
+
+`tools/pmc_kernel.sh`: six separate `rocprofv3 --kernel-trace --pmc <four SQ counters>` passes of
+`python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra` (eager launches, three steps per pass), summed per
+kernel-name family; `tools/sq_table.py` derives the shares.  SQ_BUSY_CYCLES is a sum over the 32 shader engines; SQ_WAVE_CYCLES and the
+SQ_WAIT_* / SQ_ACTIVE_* counters are in quad-cycles (ratios between them need no conversion); MFMA pipe busy =
+SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs); kernel time at 2.1 GHz.
+
+{sq}
+Raw sums:
+
+```
+{rd("sq.log")}```
+""")
 open(os.path.join(P, "r2_final_summary.md"), "w").write(f"""# Round 2 (final state) — rocprofv3 summary, MI355X, preset s @640 bf16, 32 img, graph-captured train step
 
 Produced by `bash tools/final_profile.sh` on one MI355X box and `python tools/publish_profile.py`: the default `python3 bench.py`
@@ -40,7 +55,7 @@ line (`profiles/r2_final_bench.json`: {b['value']:.0f} img/s, {b['ms_per_step']:
 
 whose per-kernel statistics are `profiles/r2_final_kernel_stats.csv` (whole run: capture warm-up, 25 replays, the instrumented
 eager step of the roofline leg).  rocprofv3's average over the conv fwd+dgrad kernels INSIDE the replayed step (k_conv_mfma +
-k_conv_ring + k_conv_halo, 170 launches: a stride-2 data gradient on a large map is several) is in the chain table below; the live
+k_conv_ring + k_conv_halo + k_conv_rows + k_dgrad2_patch) is in the chain table below; the live
 leaf timing counts such a layer as one call.
 
 ## The two chains of one replayed step (`tools/chain_breakdown.py`: cut at the optimizer launch)
