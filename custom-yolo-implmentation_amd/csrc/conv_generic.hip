@@ -20,7 +20,7 @@ int mfma_conv_launch(const ConvGeom& g, const void* src, const void* wm, const f
                      int accumulate, int dtype, hipStream_t st);
 int mfma_wgrad_eligible(int Cin, int Cout, int ldx, int ldy, int dtype, const void* x, const void* dy);
 long mfma_wgrad2_plan(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k);
-int mfma_wgrad2_slabs(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k);
+long mfma_wgrad2_ws_elems(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k);
 int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* part, void* dw_oihw, int dw_dtype, int Kpad,
                        int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st);
 int f32_conv_eligible(const ConvGeom& g, const void* src, const void* wm, const void* dst);
@@ -532,10 +532,9 @@ long yolo_conv2d_wgrad_ws_elems(const void* x, int ldx, const void* dy, int ldy,
                                 int OW, int Cout, int k, int stride, int dtype, int algo) {
     if (!supported(k, stride)) return 0;
     const int Kpad = round_up32(k * k * Cin);
-    long mats = 1;
     if (wgrad_path(x, ldx, dy, ldy, N, H, W, Cin, OH, OW, Cout, dtype, algo) == 2)
-        mats = mfma_wgrad2_slabs(Kpad, N, H, W, Cin, OH, OW, Cout, k);
-    return mats * Cout * Kpad;
+        return mfma_wgrad2_ws_elems(Kpad, N, H, W, Cin, OH, OW, Cout, k);
+    return (long)Cout * Kpad;
 }
 
 // dw_oihw[Cout][Cin][k][k] (dw_dtype) = sum over pixels of dy (x) x.  ws: fp32 scratch of

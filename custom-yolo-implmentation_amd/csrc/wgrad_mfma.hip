@@ -193,48 +193,40 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
                 }
             }
     }
-    // D rows = co ((lane>>4)*4 + r), cols = ci (lane & 15); every slab owns one [Cout][Kpad] partial matrix (plain
-    // stores: an atomic flush into one shared matrix ran at ~250 G adds/s and dominated the small layers)
-    float* part = dwp + (long)slab * a.Cout * a.Kpad;
+    // Partial sums leave as a raw register image: part[slab][tile][wave][tap][i][j][lane] is the lane's float4 accumulator
+    // (rows co = g*4 + r, column ci = lane & 15 of the 16x16 block (i, j)) -- one fully coalesced 1 KB store per accumulator
+    // block instead of four 64-byte runs per register (the [Cout][Kpad] image cost 13 of a 20x20 128->128 layer's 21 us);
+    // k_wgrad_reduce undoes the permutation while it sums the slabs.  Plain stores: an atomic flush into one shared matrix ran
+    // at ~250 G adds/s and dominated the small layers.
+    float4* part4 = reinterpret_cast<float4*>(dwp) + ((((long)slab * ntile + tile) * 4 + wave) * (NT * TCO * TCI)) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
             for (int j = 0; j < TCI; ++j) {
-                const int ci = bci + (wi * TCI + j) * 16 + i16;
-                if (ci >= a.Cin) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = bco + (wc * TCO + i) * 16 + g * 4 + r;
-                    if (co < a.Cout) part[(long)co * a.Kpad + t * a.Cin + ci] = acc[t][i][j][r];
-                }
+                const f32x4 v = acc[t][i][j];
+                part4[((t * TCO + i) * TCI + j) * 64] = make_float4(v[0], v[1], v[2], v[3]);
             }
 }
 
-// sum of the slabs' partial matrices -> OIHW gradient in the parameter's dtype (replaces memset + unpack).
-// A thread owns FOUR consecutive packed elements of one row (one 16-byte load per slab, all lanes of a wave on
-// consecutive 16-byte pieces: full cache lines); SL lanes share an element group and stride over the slabs, then combine
-// through LDS.  (The first version read 4 bytes per lane, 64-byte runs: 1.7 TB/s over 2.2 GB per step.)
+// sum of the slabs' partial images -> OIHW gradient in the parameter's dtype (replaces memset + unpack).
+// A thread owns one float4 of the register image (four co rows of one ci column of one tap: see k_wgrad2's epilogue): one
+// 16-byte load per slab, all lanes of a wave on consecutive 16-byte pieces; SL lanes share a group and stride over the slabs,
+// then combine through LDS; the four sums go to their places in [Cout][Cin][k][k].
 template <typename TO, int SL>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nslab, int Cout, int Cin, int NT,
-                                                      int Kpad, TO* __restrict__ dw) {
-    constexpr int EL = 256 / SL;                              // element groups (of 4) per workgroup
+                                                      int tco, int tci, int cot, long groups, TO* __restrict__ dw) {
+    constexpr int EL = 256 / SL;                              // float4 groups per workgroup
     __shared__ float4 red[SL][EL + 1];
     const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
-    const int K = Cin * NT, K4 = K >> 2;                      // Cin % 8 == 0: K is a multiple of 4
-    const long groups = (long)Cout * K4;
-    const long slab = (long)Cout * Kpad;
     const long gi = (long)blockIdx.x * EL + el;
-    int co = 0, k = 0;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gi < groups) {
-        co = (int)(gi / K4);
-        k = (int)(gi - (long)co * K4) * 4;                    // packed order: k = tap*Cin + ci
-        const float* p = part + (long)co * Kpad + k;
+        const float4* p = reinterpret_cast<const float4*>(part) + gi;
 #pragma unroll 4
         for (int s2 = sl; s2 < nslab; s2 += SL) {
-            const float4 v = *reinterpret_cast<const float4*>(p + s2 * slab);
+            const float4 v = p[s2 * groups];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
     }
@@ -249,24 +241,40 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
         }
     }
     if (gi < groups) {
-        const int t = k / Cin, ci = k - t * Cin;              // the four elements share the tap (Cin % 4 == 0)
-        TO* o = dw + ((long)co * Cin + ci) * NT + t;
-        o[0] = (TO)a.x; o[NT] = (TO)a.y; o[2 * NT] = (TO)a.z; o[3 * NT] = (TO)a.w;
+        const int lane = (int)(gi & 63);
+        long rest = gi >> 6;
+        const int j = (int)(rest % tci); rest /= tci;
+        const int i = (int)(rest % tco); rest /= tco;
+        const int t = (int)(rest % NT); rest /= NT;
+        const int wave = (int)(rest & 3);
+        const int tile = (int)(rest >> 2);
+        const int co = (tile % cot) * (32 * tco) + ((wave >> 1) * tco + i) * 16 + (lane >> 4) * 4;
+        const int ci = (tile / cot) * (32 * tci) + ((wave & 1) * tci + j) * 16 + (lane & 15);
+        if (ci < Cin) {
+            TO* o = dw + ((long)co * Cin + ci) * NT + t;
+            const long rs = (long)Cin * NT;
+            if (co < Cout) o[0] = (TO)a.x;
+            if (co + 1 < Cout) o[rs] = (TO)a.y;
+            if (co + 2 < Cout) o[2 * rs] = (TO)a.z;
+            if (co + 3 < Cout) o[3 * rs] = (TO)a.w;
+        }
     }
 }
 
+struct WgPlan { int to, ti, cot, cit, nslab; long per_slab; };
+
 template <typename TO>
-void launch_reduce(const float* part, int nslab, int Cout, int Cin, int NT, int Kpad, void* dw, hipStream_t st) {
-    const long groups = (long)Cout * Cin * NT / 4;
-    if (nslab >= 32)
-        hipLaunchKernelGGL((k_wgrad_reduce<TO, 8>), dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, st, part, nslab, Cout, Cin, NT, Kpad, (TO*)dw);
-    else if (nslab >= 4)
-        hipLaunchKernelGGL((k_wgrad_reduce<TO, 4>), dim3((unsigned)((groups + 63) / 64)), dim3(256), 0, st, part, nslab, Cout, Cin, NT, Kpad, (TO*)dw);
+void launch_reduce(const float* part, const WgPlan& p, int Cout, int Cin, int NT, void* dw, hipStream_t st) {
+    const long groups = (long)p.cot * p.cit * 4 * NT * p.to * p.ti * 64;
+    if (p.nslab >= 32)
+        hipLaunchKernelGGL((k_wgrad_reduce<TO, 8>), dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, st, part, p.nslab, Cout, Cin, NT, p.to, p.ti, p.cot, groups, (TO*)dw);
+    else if (p.nslab >= 4)
+        hipLaunchKernelGGL((k_wgrad_reduce<TO, 4>), dim3((unsigned)((groups + 63) / 64)), dim3(256), 0, st, part, p.nslab, Cout, Cin, NT, p.to, p.ti, p.cot, groups, (TO*)dw);
     else
-        hipLaunchKernelGGL((k_wgrad_reduce<TO, 1>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, part, nslab, Cout, Cin, NT, Kpad, (TO*)dw);
+        hipLaunchKernelGGL((k_wgrad_reduce<TO, 1>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, part, p.nslab, Cout, Cin, NT, p.to, p.ti, p.cot, groups, (TO*)dw);
 }
 
-struct WgPlan { int to, ti, cot, cit, nslab; long per_slab; };
+
 
 // Plan overrides (tile, workgroup count), 0 = automatic.  Read ONCE per process from YOLO_WG_TUNE ("to,ti,blocks,min_per")
 // and YOLO_WG_BLOCKS; tools/wg_tune.py and the plan-forcing parity tests change them through yolo_wgrad_tune_set.
@@ -394,11 +402,12 @@ extern "C" int yolo_wgrad_tune_set(int to, int ti, int blocks, int min_per) {
     return YOLO_OK;
 }
 
-// number of [Cout][Kpad] fp32 partial matrices the launch below writes (same eligibility as the first design)
-int mfma_wgrad2_slabs(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k) {
+// fp32 elements of partial-sum scratch the launch below writes: one register image of every (co, ci) tile per slab
+long mfma_wgrad2_ws_elems(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k) {
     WgArgs a = make_args(0, 0, Kpad, N, H, W, Cin, OH, OW, Cout);
-    if (a.npatch == 0) return 1;
-    return make_plan(a, k).nslab;
+    if (a.npatch == 0) return (long)Cout * Kpad;
+    const WgPlan p = make_plan(a, k);
+    return (long)p.nslab * p.cot * p.cit * k * k * (32L * p.to) * (32L * p.ti);
 }
 
 long mfma_wgrad2_plan(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k) {
@@ -408,7 +417,7 @@ long mfma_wgrad2_plan(int Kpad, int N, int H, int W, int Cin, int OH, int OW, in
     return p.to * 1000000L + p.ti * 100000L + p.nslab;
 }
 
-// part[nslab][Cout][Kpad] (fp32 scratch, need not be zeroed) <- per-slab partial gradients, then
+// part (fp32 scratch of mfma_wgrad2_ws_elems elements, need not be zeroed) <- per-slab partial gradients, then
 // dw_oihw[Cout][Cin][k][k] (dw_dtype) <- their sum
 int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* part, void* dw_oihw, int dw_dtype, int Kpad,
                        int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, hipStream_t st) {
@@ -420,9 +429,9 @@ int mfma_wgrad2_launch(const void* x, int ldx, const void* dy, int ldy, float* p
     else if (dtype == YOLO_F16) rc = launch_ks<f16_t>(a, p, k, stride, x, dy, part, st);
     else return YOLO_ERR_DTYPE;
     if (rc) return rc;
-    if (dw_dtype == YOLO_F32) launch_reduce<float>(part, p.nslab, Cout, Cin, k * k, Kpad, dw_oihw, st);
-    else if (dw_dtype == YOLO_BF16) launch_reduce<bf16_t>(part, p.nslab, Cout, Cin, k * k, Kpad, dw_oihw, st);
-    else if (dw_dtype == YOLO_F16) launch_reduce<f16_t>(part, p.nslab, Cout, Cin, k * k, Kpad, dw_oihw, st);
+    if (dw_dtype == YOLO_F32) launch_reduce<float>(part, p, Cout, Cin, k * k, dw_oihw, st);
+    else if (dw_dtype == YOLO_BF16) launch_reduce<bf16_t>(part, p, Cout, Cin, k * k, dw_oihw, st);
+    else if (dw_dtype == YOLO_F16) launch_reduce<f16_t>(part, p, Cout, Cin, k * k, dw_oihw, st);
     else return YOLO_ERR_DTYPE;
     return YOLO_LAUNCH_CHECK();
 }
