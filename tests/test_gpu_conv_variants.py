@@ -40,9 +40,9 @@ def _reset_tuning():
     lib().call("yolo_wgrad_tune_set", 0, 0, 0, 0)
 
 
-def rnd(shape, seed, scale=1.0):
+def rnd(shape, seed, scale=1.0, dtype=None):
     g = torch.Generator().manual_seed(seed)
-    return (torch.randn(*shape, generator=g) * scale).to(BF)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype or BF)
 
 
 def on_dev(t, ld=None, fill=3.0):
@@ -77,16 +77,18 @@ def assert_slice_untouched(buf, off, c, fill, what):
 
 
 def run_fwd_dgrad_case(n, cin, cout, h, w, k, s, images, ldx=None, ldy=None, stats=True, acc=(False, True), seed=0,
-                       want_plan=None):
+                       want_plan=None, dtype=None):
     """forward (+ BatchNorm statistics epilogue) and data gradient (+ accumulate form) of one shape against the CPU
     reference evaluated on `images` (conv is per image)."""
     o = ops()
     q = lib().query
+    BF = dtype or globals()["BF"]                          # the case's 16-bit type (bf16 unless the test asks for f16)
+    rel = 2.0 ** -8 if BF == torch.bfloat16 else 2.0 ** -10
     oh, ow = o.conv_out_hw(h, w, k, s)
     if want_plan is not None:
         got = q("yolo_conv2d_plan", n, h, w, cin, oh, ow, cout, k, s, 0, 0, lib().BF16)
         assert got == want_plan, f"test does not reach the variant it is written for: plan {got}, wanted {want_plan}"
-    x, wt = rnd((n, cin, h, w), seed + 1), rnd((cout, cin, k, k), seed + 2, (cin * k * k) ** -0.5).float()
+    x, wt = rnd((n, cin, h, w), seed + 1, dtype=BF), rnd((cout, cin, k, k), seed + 2, (cin * k * k) ** -0.5, dtype=BF).float()
     images = sorted(set(i for i in images if i < n))
     wp, wb = o.pack_weights(wt.to(DEV), k, s, 0, BF), o.pack_weights(wt.to(DEV), k, s, 1, BF)
     wref = wt.to(BF).float()
@@ -98,7 +100,7 @@ def run_fwd_dgrad_case(n, cin, cout, h, w, k, s, images, ldx=None, ldy=None, sta
     acc_s = o.bn_acc_new(cout, DEV) if stats else None
     y = o.conv_fwd(xd, wp, None, cout, k, s, acc_s, out=yv)
     y_ref = F.conv2d(x[images].float(), wref, None, s, k // 2)
-    assert_elem(y[images], y_ref, f"conv_fwd {(n, cin, h, w, cout, k, s)}")
+    assert_elem(y[images], y_ref, f"conv_fwd {(n, cin, h, w, cout, k, s)}", rel=rel)
     assert_slice_untouched(ybuf, yoff, cout, 5.0, "conv_fwd")
     if stats:
         yf = y.float()
@@ -109,11 +111,11 @@ def run_fwd_dgrad_case(n, cin, cout, h, w, k, s, images, ldx=None, ldy=None, sta
     # ---- data gradient
     if cin % 8:
         return
-    dy = rnd((n, cout, oh, ow), seed + 3)
+    dy = rnd((n, cout, oh, ow), seed + 3, dtype=BF)
     dyd, _, _ = on_dev(dy, ldy)
     dx_ref = torch.nn.grad.conv2d_input((len(images), cin, h, w), wref, dy[images].float(), s, k // 2)
     for accumulate in acc:
-        base = rnd((n, cin, h, w), seed + 4)
+        base = rnd((n, cin, h, w), seed + 4, dtype=BF)
         dxv, dxbuf, dxoff = on_dev(base, ldx, fill=9.0)
         if accumulate:
             o.conv_dgrad(dyd, wb, cin, h, w, k, s, acc_into=dxv)
@@ -122,7 +124,7 @@ def run_fwd_dgrad_case(n, cin, cout, h, w, k, s, images, ldx=None, ldy=None, sta
         else:
             got = o.conv_dgrad(dyd, wb, cin, h, w, k, s)
             want = dx_ref
-        assert_elem(got[images], want, f"conv_dgrad acc={accumulate} {(n, cin, h, w, cout, k, s)}")
+        assert_elem(got[images], want, f"conv_dgrad acc={accumulate} {(n, cin, h, w, cout, k, s)}", rel=rel)
         if accumulate:
             assert_slice_untouched(dxbuf, dxoff, cin, 9.0, "conv_dgrad")
 
@@ -193,6 +195,21 @@ def test_rows_kernel_16_pixel_wide_blocks(cin, cout, h, w):
     """conv_rows.hip with 10 x 16-pixel blocks on maps of any size: partial blocks in both directions"""
     lib().call("yolo_conv_tune_set", 0, -1, 14, -1, -1, 0, 0, 0)
     run_fwd_dgrad_case(3, cin, cout, h, w, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=4006, seed=cin)
+
+
+@pytest.mark.parametrize("force,cin,cout,h,w,plan", [(8, 64, 128, 23, 20, 4003), (12, 96, 72, 13, 40, 4004), (14, 64, 64, 23, 37, 4006)])
+def test_rows_kernel_f16(force, cin, cout, h, w, plan):
+    """the f16 instantiations of conv_rows.hip (config 5 trains in f16), at f16's tighter tolerance"""
+    lib().call("yolo_conv_tune_set", 0, -1, force, -1, -1, 0, 0, 0)
+    run_fwd_dgrad_case(3, cin, cout, h, w, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=plan, seed=force,
+                       dtype=torch.float16)
+
+
+def test_stride2_dgrad_patch_kernel_f16():
+    q = lib().query
+    got = [q("yolo_conv2d_plan", 3, 84, 100, 72, 42, 50, 96, 3, 2, 1, c, lib().F16) for c in range(4)]
+    assert all(g == 5008 for g in got), got
+    run_fwd_dgrad_case(3, 72, 96, 84, 100, 3, 2, images=[0, 1, 2], ldx=72 + 32, ldy=96 + 16, stats=False, seed=5, dtype=torch.float16)
 
 
 @pytest.mark.parametrize("to,ti", [(1, 1), (1, 2), (2, 1), (2, 2)])
