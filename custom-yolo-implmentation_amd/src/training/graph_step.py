@@ -176,8 +176,11 @@ class TrainStepRunner:
             with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                 preds, anchors, strides = self.model(images)
                 loss, ld = self.criterion(preds, packed, anchors, strides)
+            # the loss tensor is the fused loss node's own output: the seed of backward() (ones) reaches it unchanged
+            F_.UNIT_LOSS_SEED = type(loss.grad_fn).__name__ == "DflQflLossBackward" and os.environ.get("YOLO_UNIT_SEED", "1") == "1"
             loss.backward()
         finally:
+            F_.UNIT_LOSS_SEED = False
             if self.staged:
                 self.model.stage_cut = None
             if not self.staged:
