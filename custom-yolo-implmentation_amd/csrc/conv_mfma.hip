@@ -546,6 +546,10 @@ static int rows_variant(const ConvGeom& g) {
     const int el = rows_conv_eligible(g);
     if (!el) return 0;
     if ((v >= 0 && v < 5) || v == 9) return 0;               // 9: this kernel off, everything else automatic (A/B runs)
+    // narrow layers (fewer than 64 destination channels): 20 x 16 pixels x 32 channels.  Ahead of the gather kernels with a full
+    // 32-channel source chunk (64->32 @80x80 forward 28.4 -> 21.0 us, its 32->64 data gradient 26.1 -> 18.6; 32->16 @160x160
+    // forward 41.9 -> 36.5), behind them with a 16-channel source (half-empty chunks): 16 = forced, tests
+    if (el == 3) return (v == 16 || ((v < 0 || v == 5) && g.Cs % 32 == 0)) ? 7 : 0;
     if (v == 14) return 6;                                   // 16-pixel-wide blocks, any map width
     // wider maps: 10 x 16-pixel blocks x 64 channels beat the halo kernel where the layer has exactly one 64-channel tile
     // (64->64 @80x80 35 -> 31 us forward, 31.5 -> 26.8 data gradient; 128->64 forward 51.5 -> 41.5; 64->64 @160x160 104 -> 97)

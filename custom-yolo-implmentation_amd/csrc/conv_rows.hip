@@ -36,10 +36,10 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     constexpr int WGN = NWAVE / WGM;                         // waves: WGM groups of five pixel tiles x WGN channel groups
     constexpr int NTHR = 64 * NWAVE, BN = WGN * WN * 16;
     constexpr int HP = ((HPX + 15) / 16 + NWAVE - 1) / NWAVE; // patch pieces (16 pixels x 64 bytes) per wave
-    constexpr int DW = 3 * BN / 16 / NWAVE;                  // weight pieces (16 rows x 64 bytes) per wave and step: 3 taps x BN rows
-    constexpr int HBUF = NWAVE * HP * 1024, STAGE = 3 * BN * 64;     // bytes: one patch buffer, one weight stage
+    constexpr int DW = (3 * BN / 16 + NWAVE - 1) / NWAVE;    // weight pieces (16 rows x 64 bytes) per wave and step: 3 taps x BN rows (+ idle pieces)
+    constexpr int HBUF = NWAVE * HP * 1024, STAGE = NWAVE * DW * 1024;     // bytes: one patch buffer, one weight stage
     constexpr int OOB = (int)0x80000000;
-    static_assert(R * W == WGM * 80 && NST >= 3 && NST <= 4 && NWAVE == 4 && (3 * BN / 16) % NWAVE == 0, "block shape");
+    static_assert(R * W == WGM * 80 && NST >= 3 && NST <= 4 && NWAVE == 4, "block shape");
     using ops = mfma_ops<T>;
     using frag = typename ops::frag;
     extern __shared__ __attribute__((aligned(1024))) char rows_smem[];        // [2][HBUF] patches, [NST][STAGE] weights
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
         const int px = (wave * HP + i) * 16 + (lane >> 2), ck = (lane & 3) ^ ((px >> 1) & 3);
         const int hy = px / HWID, hx = px - hy * HWID;
         const bool ok = px < HPX && (unsigned)(y0 - 1 + hy) < (unsigned)g.Hs && (unsigned)(x0 + hx - 1) < (unsigned)g.Ws;
-        hvoff[i] = ok ? ((hy * g.Ws + hx) * g.lds + ck * 8) * 2 : OOB;
+        hvoff[i] = (ok && ck * 8 < g.Cs) ? ((hy * g.Ws + hx) * g.lds + ck * 8) * 2 : OOB;      // ck*8 >= Cs: a 16-channel source fills half a chunk
     }
     // scalar origin of the patch: pixel (n, y0-1, -1) relative to the shifted descriptor base (never negative)
     const int hsoff0 = (((n * g.Hs + y0 - 1) * g.Ws + x0 - 1) * g.lds + shift) * 2;
@@ -73,9 +73,9 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
         const int rs = (wave * DW + j) * 16 + (lane >> 2);   // row of the stage: (tap of the step, channel)
         const int tl = rs / BN, row = rs - tl * BN;
         const int kseg = (lane & 3) ^ ((-(row >> 2)) & 3);   // k_conv_mfma's swizzle
-        wvoff[j] = (cd0 + row < g.Cd) ? ((cd0 + row) * g.Kpad + tl * g.Cs + kseg * 8) * 2 : OOB;
+        wvoff[j] = (tl < 3 && cd0 + row < g.Cd && kseg * 8 < g.Cs) ? ((cd0 + row) * g.Kpad + tl * g.Cs + kseg * 8) * 2 : OOB;
     }
-    const int nchunk = g.Cs / BK, nit = nchunk * 3;
+    const int nchunk = (g.Cs + BK - 1) / BK, nit = nchunk * 3;   // Cs is a multiple of 32, or 16 (one half-filled chunk)
     auto issue_halo = [&](int chunk) {                       // chunks past the end: zero-size descriptor, same piece count
         const __amdgpu_buffer_rsrc_t rsa =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src) - shift, 0, chunk < nchunk ? a_bytes : 0, 0x00020000);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
 template <typename T, int W, int WGM, int NWAVE, int WN, int NST>
 int launch_rows(const GeomDev& d, const void* src, const void* wm, const float* bias, void* dst, int accumulate, hipStream_t st) {
     constexpr int R = WGM * 80 / W, BN = (NWAVE / WGM) * WN * 16, HPX = (R + 2) * (W == 16 ? 18 : W + 8);
-    constexpr size_t lds = 2 * (size_t)(NWAVE * (((HPX + 15) / 16 + NWAVE - 1) / NWAVE)) * 1024 + (size_t)NST * 3 * BN * 64;
+    constexpr size_t lds = 2 * (size_t)(NWAVE * (((HPX + 15) / 16 + NWAVE - 1) / NWAVE)) * 1024 + (size_t)NST * NWAVE * ((3 * BN / 16 + NWAVE - 1) / NWAVE) * 1024;
     const int th = (d.Hg + R - 1) / R, tw = W == 16 ? (d.Wg + 15) / 16 : 1, tn = (d.Cd + BN - 1) / BN;
     const dim3 grid((unsigned)(d.N * th * tw * tn));
     hipError_t e;
@@ -269,13 +269,15 @@ int launch_rows(const GeomDev& d, const void* src, const void* wm, const float* 
 
 // Shapes the row-block kernel takes: the nine taps of a 3x3 conv, stride 1 in source and destination, maps exactly 20 or
 // 40 pixels wide, source channels a multiple of 32, at least 64 destination channels.
-// rows_conv_eligible: 1 = full-row blocks (20- / 40-wide maps), 2 = only the 16-pixel-wide blocks (variant 6), 0 = neither
+// rows_conv_eligible: 1 = full-row blocks (20- / 40-wide maps), 2 = only the 16-pixel-wide blocks (variant 6), 3 = only the
+// 16-pixel-wide blocks with a 32-channel tile (variant 7: fewer than 64 destination channels or a 16-channel source), 0 = none
 int rows_conv_eligible(const ConvGeom& g) {
-    if (!(g.sstride == 1 && g.ostep == 1 && g.ooff_h == 0 && g.ooff_w == 0 && g.ntaps == 9 && g.Cs % 32 == 0 && g.Cd >= 64 &&
+    if (!(g.sstride == 1 && g.ostep == 1 && g.ooff_h == 0 && g.ooff_w == 0 && g.ntaps == 9 && (g.Cs % 32 == 0 || g.Cs == 16) && g.Cd >= 16 &&
           g.Cd % 8 == 0 && g.Hg == g.Hs && g.Wg == g.Ws && g.Hd == g.Hg && g.Wd == g.Wg))
         return 0;
     for (int t = 0; t < 9; ++t)
         if (g.dh[t] < -1 || g.dh[t] > 1 || g.dw[t] < -1 || g.dw[t] > 1) return 0;
+    if (g.Cd < 64 || g.Cs == 16) return 3;                   // narrow layers: variant 7 only
     return (g.Wg == 20 || g.Wg == 40) ? 1 : 2;
 }
 
@@ -298,6 +300,7 @@ int rows_conv_launch(const ConvGeom& g, int variant, const void* src, const void
     }
 #define ROWS_T(T_)                                                                                                   \
     if (variant == 6) return launch_rows<T_, 16, 2, 4, 2, 3>(d, src, wm, bias, dst, accumulate, st);   /* 10 x 16 pixels x 64 ch */ \
+    if (variant == 7) return launch_rows<T_, 16, 4, 4, 2, 3>(d, src, wm, bias, dst, accumulate, st);   /* 20 x 16 pixels x 32 ch */ \
     if (g.Wg == 20) { ROWS_W(T_, 20) }                                                                               \
     ROWS_W(T_, 40)
     if (dtype == YOLO_BF16) { ROWS_T(bf16_t) }

@@ -197,6 +197,13 @@ def test_rows_kernel_16_pixel_wide_blocks(cin, cout, h, w):
     run_fwd_dgrad_case(3, cin, cout, h, w, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=4006, seed=cin)
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(16, 32, 23, 37), (32, 16, 41, 16), (64, 24, 20, 33), (16, 16, 7, 50)])
+def test_rows_kernel_narrow_layers(cin, cout, h, w):
+    """conv_rows.hip, 20 x 16-pixel blocks x 32 channels: fewer than 64 destination channels, 16-channel sources (half a chunk)"""
+    lib().call("yolo_conv_tune_set", 0, -1, 16, -1, -1, 0, 0, 0)
+    run_fwd_dgrad_case(3, cin, cout, h, w, 3, 1, images=[0, 1, 2], ldx=cin + 32, ldy=cout + 16, want_plan=4007, seed=cin + cout)
+
+
 @pytest.mark.parametrize("force,cin,cout,h,w,plan", [(8, 64, 128, 23, 20, 4003), (12, 96, 72, 13, 40, 4004), (14, 64, 64, 23, 37, 4006)])
 def test_rows_kernel_f16(force, cin, cout, h, w, plan):
     """the f16 instantiations of conv_rows.hip (config 5 trains in f16), at f16's tighter tolerance"""
