@@ -20,7 +20,7 @@ torch.manual_seed(100 + rank)                       # different initial weights:
 model = Model(csp=[False, True], depth=[1] * 6, width=[3, 16, 32, 64, 128, 256], num_classes=80)
 model = prepare_ddp_model(model=model, device_id=0, config={"precision": "bfloat16", "captured_step": True}, world_size=world,
                           device="cuda")
-assert type(model) is Model
+assert type(getattr(model, "module", model)) is Model     # DDP-wrapped since round 2 (the runner steps the inner module)
 tr, va = get_data_loaders("/nonexistent/train", "/nonexistent/val", "", "", batch_size=4, is_test=True, device="cuda",
                           num_classes=80, res=160)
 opt, sched = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
