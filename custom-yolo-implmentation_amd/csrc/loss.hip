@@ -69,8 +69,7 @@ __global__ void k_assign(int A, const float4* __restrict__ pbox, const float* __
     const float m2x = -2.f * gx, m2y = -2.f * gy;
     float best = INFINITY;
     int bi = 0x7fffffff;
-    for (int a = threadIdx.x; a < A; a += blockDim.x) {
-        float4 b = pb[a];
+    auto consider = [&](int a, const float4& b) {
         float bn = __fadd_rn(__fmul_rn(b.x, b.x), __fmul_rn(b.y, b.y));
         float acc = __fmul_rn(m2x, b.x);
         acc = __fmaf_rn(m2y, b.y, acc);
@@ -78,7 +77,16 @@ __global__ void k_assign(int A, const float4* __restrict__ pbox, const float* __
         acc = __fadd_rn(bn, acc);
         float dist = __fsqrt_rn(fmaxf(acc, 0.f));
         if (dist < best || (dist != dist && best == best)) { best = dist; bi = a; }   // NaN wins like argmin
+    };
+    // four boxes per thread in flight, considered in the same order as one at a time (33 dependent round trips for 8400
+    // anchors were the kernel's 16 us)
+    const int bd = blockDim.x;
+    int a = threadIdx.x;
+    for (; a + 3 * bd < A; a += 4 * bd) {
+        const float4 b0 = pb[a], b1 = pb[a + bd], b2 = pb[a + 2 * bd], b3 = pb[a + 3 * bd];
+        consider(a, b0); consider(a + bd, b1); consider(a + 2 * bd, b2); consider(a + 3 * bd, b3);
     }
+    for (; a < A; a += bd) consider(a, pb[a]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         float ob = __shfl_xor(best, o, 64);
