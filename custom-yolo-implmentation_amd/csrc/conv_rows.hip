@@ -252,14 +252,13 @@ int launch_rows(const GeomDev& d, const void* src, const void* wm, const float* 
     constexpr size_t lds = 2 * (size_t)(NWAVE * (((HPX + 15) / 16 + NWAVE - 1) / NWAVE)) * 1024 + (size_t)NST * NWAVE * ((3 * BN / 16 + NWAVE - 1) / NWAVE) * 1024;
     const int th = (d.Hg + R - 1) / R, tw = W == 16 ? (d.Wg + 15) / 16 : 1, tn = (d.Cd + BN - 1) / BN;
     const dim3 grid((unsigned)(d.N * th * tw * tn));
-    hipError_t e;
     if (accumulate) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
+        if (once != hipSuccess) return (int)once;
         hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tw, tn);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
+        if (once != hipSuccess) return (int)once;
         hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tw, tn);
     }
     return YOLO_LAUNCH_CHECK();

@@ -215,14 +215,13 @@ int launch_up2(const Up2Geom& d, const void* src, const void* wm, void* dst, int
     constexpr size_t lds = (size_t)(2 * NW * HP + NST * NW * DW) * 1024;
     const int th = (d.Hs + TH - 1) / TH, tw = (d.Ws + 15) / 16, tn = (d.Cd + BN - 1) / BN;
     const dim3 grid((unsigned)(d.N * th * tw * tn));
-    hipError_t e;
     if (accumulate) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
+        if (once != hipSuccess) return (int)once;
         hipLaunchKernelGGL((k_dgrad2_patch<T, TH, BN, WM, NST, true>), grid, dim3(NTHR), lds, st, d, (const T*)src, (const T*)wm, (T*)dst, th, tw, tn);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
+        if (once != hipSuccess) return (int)once;
         hipLaunchKernelGGL((k_dgrad2_patch<T, TH, BN, WM, NST, false>), grid, dim3(NTHR), lds, st, d, (const T*)src, (const T*)wm, (T*)dst, th, tw, tn);
     }
     return YOLO_LAUNCH_CHECK();
