@@ -65,6 +65,22 @@ static inline int hip_status(hipError_t e) { return e == hipSuccess ? YOLO_OK : 
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Dynamic LDS above the default limit needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel.  The attribute
+// belongs to the (function, device) pair: `done` is the call site's per-instantiation bitmask of devices that have it,
+// set only after a SUCCESSFUL call (a failure is retried by the next launch, not cached; a second device of the same
+// process gets its own call).  Benign race: two threads may both set the attribute once.
+static inline int yolo_allow_dyn_lds(const void* fn, size_t bytes, unsigned long long& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&done, __ATOMIC_RELAXED) & bit) return YOLO_OK;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
+    return YOLO_OK;
+}
+
 // Zero fill as a KERNEL.  hipMemsetAsync becomes a memset node when the stream is captured into a hipGraph, and on
 // this stack replays of such a graph did not always order that node before the kernels that accumulate into the
 // buffer (BatchNorm statistics came out wrong from the second replay on, run-dependent).  Kernel nodes of a

@@ -253,12 +253,12 @@ int launch_rows(const GeomDev& d, const void* src, const void* wm, const float* 
     const int th = (d.Hg + R - 1) / R, tw = W == 16 ? (d.Wg + 15) / 16 : 1, tn = (d.Cd + BN - 1) / BN;
     const dim3 grid((unsigned)(d.N * th * tw * tn));
     if (accumulate) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
-        if (once != hipSuccess) return (int)once;
+        static unsigned long long done = 0;         // per instantiation: devices that have the attribute
+        if (int e = yolo_allow_dyn_lds(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), lds, done)) return e;
         hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, true>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tw, tn);
     } else {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
-        if (once != hipSuccess) return (int)once;
+        static unsigned long long done = 0;         // per instantiation: devices that have the attribute
+        if (int e = yolo_allow_dyn_lds(reinterpret_cast<const void*>(k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), lds, done)) return e;
         hipLaunchKernelGGL((k_conv_rows<T, W, WGM, NWAVE, WN, NST, false>), grid, dim3(64 * NWAVE), lds, st, d, (const T*)src, (const T*)wm, bias, (T*)dst, th, tw, tn);
     }
     return YOLO_LAUNCH_CHECK();

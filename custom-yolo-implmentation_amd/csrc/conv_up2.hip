@@ -216,12 +216,12 @@ int launch_up2(const Up2Geom& d, const void* src, const void* wm, void* dst, int
     const int th = (d.Hs + TH - 1) / TH, tw = (d.Ws + 15) / 16, tn = (d.Cd + BN - 1) / BN;
     const dim3 grid((unsigned)(d.N * th * tw * tn));
     if (accumulate) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
-        if (once != hipSuccess) return (int)once;
+        static unsigned long long done = 0;         // per instantiation: devices that have the attribute
+        if (int e = yolo_allow_dyn_lds(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, true>), lds, done)) return e;
         hipLaunchKernelGGL((k_dgrad2_patch<T, TH, BN, WM, NST, true>), grid, dim3(NTHR), lds, st, d, (const T*)src, (const T*)wm, (T*)dst, th, tw, tn);
     } else {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per instantiation
-        if (once != hipSuccess) return (int)once;
+        static unsigned long long done = 0;         // per instantiation: devices that have the attribute
+        if (int e = yolo_allow_dyn_lds(reinterpret_cast<const void*>(k_dgrad2_patch<T, TH, BN, WM, NST, false>), lds, done)) return e;
         hipLaunchKernelGGL((k_dgrad2_patch<T, TH, BN, WM, NST, false>), grid, dim3(NTHR), lds, st, d, (const T*)src, (const T*)wm, (T*)dst, th, tw, tn);
     }
     return YOLO_LAUNCH_CHECK();

@@ -297,6 +297,27 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // its prologue.  Workgroup (0, y) also publishes mean / invstd / running statistics (forward) or
 // dgamma / dbeta (backward).
 // ---------------------------------------------------------------------------------------------
+// BatchNorm parameters (gamma, beta -> dgamma, dbeta) and buffers (running statistics) in their own element type:
+// fp32 under DDP / autocast, the low-precision parameter dtype under FSDP mixed precision, whose policy casts
+// parameters AND buffers (reference src/training/utils_train.py:84-89,146-153).  Read / written once per channel in
+// the prologues, arithmetic in fp32 / double as before, one rounding on the way out.
+struct PIn {
+    const void* p; int dt;
+    __device__ __forceinline__ float ld(int i) const {
+        return dt == YOLO_F32 ? ((const float*)p)[i] : dt == YOLO_BF16 ? (float)((const bf16_t*)p)[i] : (float)((const f16_t*)p)[i];
+    }
+};
+struct PIo {
+    void* p; int dt;
+    __device__ __forceinline__ float ld(int i) const {
+        return dt == YOLO_F32 ? ((const float*)p)[i] : dt == YOLO_BF16 ? (float)((const bf16_t*)p)[i] : (float)((const f16_t*)p)[i];
+    }
+    __device__ __forceinline__ void st(int i, float v) const {
+        if (dt == YOLO_F32) ((float*)p)[i] = v; else if (dt == YOLO_BF16) ((bf16_t*)p)[i] = (bf16_t)v; else ((f16_t*)p)[i] = (f16_t)v;
+    }
+};
+static inline bool pdt_ok(int dt) { return dt == YOLO_F32 || dt == YOLO_BF16 || dt == YOLO_F16; }
+
 constexpr int BN_REPL = 8;
 
 template <int V>
@@ -385,8 +406,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 }
 
 // acc[8][2][C] -> mean, invstd, scale, shift (+ running statistics): one thread per channel, 16 loads
-__global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, int C, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+__global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, int C, PIn gamma,
+                                  PIn beta, PIo rmean, PIo rvar,
                                   float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
                                   float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -400,13 +421,13 @@ __global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, in
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
     invstd[c] = is;
-    const float g = gamma[c] * is;
+    const float g = gamma.ld(c) * is;
     scale[c] = g;
-    shift[c] = beta[c] - (float)m * g;
-    if (rmean) {
+    shift[c] = beta.ld(c) - (float)m * g;
+    if (rmean.p) {
         const double unb = count > 1.f ? var * (count / (count - 1.0)) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        rmean.st(c, (1.f - momentum) * rmean.ld(c) + momentum * (float)m);
+        rvar.st(c, (1.f - momentum) * rvar.ld(c) + momentum * (float)unb);
     }
 }
 
@@ -416,8 +437,8 @@ __global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, in
 // k_bn_finalize_acc.
 template <typename T, int V, int ACT>
 __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ y, int ldy, const float* __restrict__ acc, float count,
-                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
-                        float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean_out,
+                        PIn gamma, PIn beta, PIo rmean,
+                        PIo rvar, float momentum, float eps, float* __restrict__ mean_out,
                         float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
                         const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C, int act, int tpr) {
     extern __shared__ float cf[];                            // [2][cw]: scale, shift of this workgroup's channels
@@ -435,17 +456,17 @@ __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ 
             double var = q / count - m * m;
             if (var < 0.0) var = 0.0;
             const float is = (float)(1.0 / sqrt(var + (double)eps));
-            g = gamma[c] * is;
-            sh0 = beta[c] - (float)m * g;
+            g = gamma.ld(c) * is;
+            sh0 = beta.ld(c) - (float)m * g;
             if (blockIdx.x == 0) {
                 mean_out[c] = (float)m;
                 invstd_out[c] = is;
                 scale_out[c] = g;
                 shift_out[c] = sh0;
-                if (rmean) {
+                if (rmean.p) {
                     const double unb = count > 1.f ? var * (count / (count - 1.0)) : var;
-                    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-                    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+                    rmean.st(c, (1.f - momentum) * rmean.ld(c) + momentum * (float)m);
+                    rvar.st(c, (1.f - momentum) * rvar.ld(c) + momentum * (float)unb);
                 }
             }
         }
@@ -495,9 +516,9 @@ template <typename T, int V, int ACT>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
                               const float* __restrict__ scale, const float* __restrict__ shift,
-                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                              PIn gamma, const float* __restrict__ mean,
                               const float* __restrict__ invstd, const float* __restrict__ acc, float count,
-                              float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ dy, int lddy,
+                              PIo dgamma, PIo dbeta, T* __restrict__ dy, int lddy,
                               long npix, int C, int act, int tpr) {
     extern __shared__ float cf[];                            // [5][cw]: scale, shift, A, B, D
     const int cv = C / V;
@@ -512,12 +533,12 @@ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __re
             for (int r = 0; r < BN_REPL; ++r) { s += acc[(long)r * 2 * C + c]; q += acc[(long)r * 2 * C + C + c]; }
             const double is = invstd[c], mu = mean[c];
             q = is * (q - mu * s);                           // sum(dz*yhat)
-            const double k0 = (double)gamma[c] * is, c1 = s / count, c2 = q / count;
+            const double k0 = (double)gamma.ld(c) * is, c1 = s / count, c2 = q / count;
             v0 = scale[c]; v1 = shift[c];
             v2 = (float)k0;
             v3 = (float)(-k0 * c2 * is);
             v4 = (float)(-k0 * c1 + k0 * c2 * mu * is);
-            if (blockIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)q; }
+            if (blockIdx.x == 0) { dbeta[c] = (float)s; dgamma.ld(c) = (float)q; }
         }
         cf[t] = v0; cf[cw + t] = v1; cf[2 * cw + t] = v2; cf[3 * cw + t] = v3; cf[4 * cw + t] = v4;
     }
@@ -580,8 +601,8 @@ __device__ __forceinline__ int fin_reduce(const float* __restrict__ partial, int
 // finalize for training-mode BN: batch mean / biased var -> invstd, scale, shift; running stats
 // updated with momentum and the unbiased variance (torch.nn.BatchNorm2d semantics).
 __global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, float count, int C,
-                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                              PIn gamma, PIn beta,
+                              PIo rmean, PIo rvar, float momentum, float eps,
                               float* __restrict__ mean, float* __restrict__ invstd,
                               float* __restrict__ scale, float* __restrict__ shift) {
     double s, q;
@@ -593,38 +614,38 @@ __global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, float
     float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
     invstd[c] = is;
-    float g = gamma[c] * is;
+    float g = gamma.ld(c) * is;
     scale[c] = g;
-    shift[c] = beta[c] - (float)m * g;
-    if (rmean) {
+    shift[c] = beta.ld(c) - (float)m * g;
+    if (rmean.p) {
         double unb = count > 1.f ? var * (count / (count - 1.0)) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        rmean.st(c, (1.f - momentum) * rmean.ld(c) + momentum * (float)m);
+        rvar.st(c, (1.f - momentum) * rvar.ld(c) + momentum * (float)unb);
     }
 }
 
-__global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+__global__ void k_bn_eval_coeffs(PIn gamma, PIn beta,
+                                 PIn rmean, PIn rvar, float eps,
                                  int C, float* __restrict__ scale, float* __restrict__ shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float g = gamma[c] / sqrtf(rvar[c] + eps);
+    float g = gamma.ld(c) / sqrtf(rvar.ld(c) + eps);
     scale[c] = g;
-    shift[c] = beta[c] - rmean[c] * g;
+    shift[c] = beta.ld(c) - rmean.ld(c) * g;
 }
 
 // backward finalize: dgamma = sum dz*yhat, dbeta = sum dz, coef = [gamma*invstd, dbeta/m, dgamma/m]
 __global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, float count, int C,
-                                  const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+                                  PIn gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  PIo dgamma, PIo dbeta, float* __restrict__ coef) {
     double s, q;
     const int c = fin_reduce(partial, nblk, C, s, q);
     if (c < 0) return;
     q = (double)invstd[c] * (q - (double)mean[c] * s);      // partial rows hold sum(dz*y): -> sum(dz*yhat)
     dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
+    dgamma.ld(c) = (float)q;
     // dy = k0*(dz - c1 - yhat*c2), yhat = (y-mean)*invstd  ==  A*dz + B*y + D  (three constants per channel)
-    const double k0 = (double)gamma[c] * invstd[c], c1 = s / count, c2 = q / count;
+    const double k0 = (double)gamma.ld(c) * invstd[c], c1 = s / count, c2 = q / count;
     coef[c] = (float)k0;
     coef[C + c] = (float)(-k0 * c2 * invstd[c]);
     coef[2 * C + c] = (float)(-k0 * c1 + k0 * c2 * (double)mean[c] * invstd[c]);
@@ -1108,18 +1129,21 @@ int yolo_bn_stats(const void* y, int ldy, long npix, int C, int dtype, float* pa
     return launch_reduce(0, y, ldy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, npix, C, 0, dtype, partial, nblk, st);
 }
 
-int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* beta,
-                     float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                     float* invstd, float* scale, float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk, (float)count, C, gamma,
-                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const void* gamma, const void* beta,
+                     void* running_mean, void* running_var, float momentum, float eps, float* mean,
+                     float* invstd, float* scale, float* shift, int pdtype, int bdtype, hipStream_t st) {
+    if (!pdt_ok(pdtype) || !pdt_ok(bdtype)) return YOLO_ERR_DTYPE;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk, (float)count, C,
+                       PIn{gamma, pdtype}, PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps,
+                       mean, invstd, scale, shift);
     return YOLO_LAUNCH_CHECK();
 }
 
-int yolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                        float eps, int C, float* scale, float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ceil_div(C, 128)), dim3(128), 0, st, gamma, beta, running_mean,
-                       running_var, eps, C, scale, shift);
+int yolo_bn_eval_coeffs(const void* gamma, const void* beta, const void* running_mean, const void* running_var,
+                        float eps, int C, float* scale, float* shift, int pdtype, int bdtype, hipStream_t st) {
+    if (!pdt_ok(pdtype) || !pdt_ok(bdtype)) return YOLO_ERR_DTYPE;
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ceil_div(C, 128)), dim3(128), 0, st, PIn{gamma, pdtype}, PIn{beta, pdtype},
+                       PIn{running_mean, bdtype}, PIn{running_var, bdtype}, eps, C, scale, shift);
     return YOLO_LAUNCH_CHECK();
 }
 
@@ -1147,10 +1171,11 @@ int yolo_bn_act_bwd_reduce(const void* dout, int ldd, const void* y, int ldy, co
     return launch_reduce(1, y, ldy, dout, ldd, scale, shift, mean, invstd, npix, C, act, dtype, partial, nblk, st);
 }
 
-int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* mean,
-                         const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const void* gamma, const float* mean,
+                         const float* invstd, void* dgamma, void* dbeta, float* coef, int pdtype, hipStream_t st) {
+    if (!pdt_ok(pdtype)) return YOLO_ERR_DTYPE;
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk,
-                       (float)count, C, gamma, mean, invstd, dgamma, dbeta, coef);
+                       (float)count, C, PIn{gamma, pdtype}, mean, invstd, PIo{dgamma, pdtype}, PIo{dbeta, pdtype}, coef);
     return YOLO_LAUNCH_CHECK();
 }
 
@@ -1197,29 +1222,31 @@ int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int dtype, float
     return launch_acc(0, y, ldy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, npix, C, 0, dtype, acc, st);
 }
 
-int yolo_bn_finalize_acc(const float* acc, long count, int C, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                         float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_finalize_acc, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, (float)count, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+int yolo_bn_finalize_acc(const float* acc, long count, int C, const void* gamma, const void* beta, void* running_mean,
+                         void* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                         float* shift, int pdtype, int bdtype, hipStream_t st) {
+    if (!pdt_ok(pdtype) || !pdt_ok(bdtype)) return YOLO_ERR_DTYPE;
+    hipLaunchKernelGGL(k_bn_finalize_acc, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, (float)count, C, PIn{gamma, pdtype},
+                       PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps, mean, invstd, scale, shift);
     return YOLO_LAUNCH_CHECK();
 }
 
-int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const float* gamma, const float* beta,
-                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const void* gamma, const void* beta,
+                          void* running_mean, void* running_var, float momentum, float eps, float* mean, float* invstd,
                           float* scale, float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C,
-                          int act, int dtype, hipStream_t st) {
+                          int act, int dtype, int pdtype, int bdtype, hipStream_t st) {
+    if (!pdt_ok(pdtype) || !pdt_ok(bdtype)) return YOLO_ERR_DTYPE;
     YOLO_DISPATCH_T(dtype, {
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(out, ldout, C) && (!res || vec_ok<T>(res, ldres, C));
         PICK_V(T, ok, {
             const RsPlan pl = rs_plan(npix, C / V);
             if (act)
                 hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 1>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
-                               (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                               (const T*)y, ldy, acc, (float)count, PIn{gamma, pdtype}, PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps,
                                mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr);
             else
                 hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 0>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
-                               (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                               (const T*)y, ldy, acc, (float)count, PIn{gamma, pdtype}, PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps,
                                mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr);
         });
     });
@@ -1233,21 +1260,22 @@ int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, co
 }
 
 int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift,
-                                const float* gamma, const float* mean, const float* invstd, const float* acc, long count,
-                                float* dgamma, float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype,
-                                hipStream_t st) {
+                                const void* gamma, const float* mean, const float* invstd, const float* acc, long count,
+                                void* dgamma, void* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype,
+                                int pdtype, hipStream_t st) {
+    if (!pdt_ok(pdtype)) return YOLO_ERR_DTYPE;
     YOLO_DISPATCH_T(dtype, {
         bool ok = vec_ok<T>(y, ldy, C) && vec_ok<T>(dout, ldd, C) && vec_ok<T>(dy, lddy, C);
         PICK_V(T, ok, {
             const RsPlan pl = rs_plan(npix, C / V);
             if (act)
                 hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 1>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
-                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
-                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr);
+                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, PIn{gamma, pdtype}, mean, invstd, acc, (float)count,
+                               PIo{dgamma, pdtype}, PIo{dbeta, pdtype}, (T*)dy, lddy, npix, C, act, pl.tpr);
             else
                 hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 0>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
-                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
-                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr);
+                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, PIn{gamma, pdtype}, mean, invstd, acc, (float)count,
+                               PIo{dgamma, pdtype}, PIo{dbeta, pdtype}, (T*)dy, lddy, npix, C, act, pl.tpr);
         });
     });
     return YOLO_LAUNCH_CHECK();

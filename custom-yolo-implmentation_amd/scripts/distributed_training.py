@@ -67,9 +67,11 @@ def main(args):
         use_wandb = use_wandb and run is not None
 
         model = Model(**model_cfg["config"], num_classes=model_cfg["num_classes"])
-        # the training step as replayed hipGraphs is the default in ddp mode (optional key `training.captured_step: false`
-        # keeps the reference's eager loop)
-        captured = None if bool(tr_cfg.get("captured_step", True)) else False
+        # the training step as replayed hipGraphs: default in ddp mode on one GPU, opt-in with more ranks (optional key
+        # `training.captured_step`: true = everywhere, false = the reference's eager loop); optional key
+        # `training.ddp.grad_compress: bf16` = bf16 gradient buckets in the captured step (default: fp32, as the reference)
+        captured = tr_cfg.get("captured_step", None)
+        captured = None if captured is None else bool(captured)
         model = WRAP[args.mode](model=model, device_id=gpu, config=tr_cfg[args.mode], world_size=world_size, device=args.device)
         print(f"[INFO] {args.mode.upper()} model initialzed")
         model = model.to(args.device)
@@ -93,7 +95,8 @@ def main(args):
               num_classes=model_cfg["num_classes"], rank=rank, use_wandb=use_wandb, wandb_instance=run,
               log_interval=tr_cfg.get("log_interval", 10), checkpoint_dir=ckpt_dir,
               iou_threshold=tr_cfg.get("iou_threshold", 0.5), conf_threshold=tr_cfg.get("conf_threshold", 0.25),
-              distributed_mode=args.mode, precision=args.precision, captured_step=captured)
+              distributed_mode=args.mode, precision=args.precision, captured_step=captured,
+              grad_compress=(tr_cfg.get("ddp") or {}).get("grad_compress"))
     finally:
         if run is not None:
             import wandb

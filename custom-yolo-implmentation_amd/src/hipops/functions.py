@@ -32,6 +32,18 @@ def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
+DETERMINISTIC = os.environ.get("YOLO_DETERMINISTIC", "") == "1"
+
+
+def deterministic_stats():
+    """Process-wide deterministic mode: `torch.use_deterministic_algorithms(True)` (or YOLO_DETERMINISTIC=1, or
+    `functions.DETERMINISTIC = True`).  The default training path sums the BatchNorm batch statistics with 8-way
+    replicated float atomics (conv / depthwise / stem epilogues, k_channel_acc), whose order differs from run to run;
+    in this mode every statistic goes through the fixed-order two-level reduction, so a step is bit-reproducible (the
+    reference's CPU path is).  Cost: one more read of every conv output in forward, two finalize launches per layer."""
+    return DETERMINISTIC or torch.are_deterministic_algorithms_enabled()
+
+
 _SIDE = {}
 FOLD_BN_FINALIZE = True     # BN scale/shift are derived in the prologue of the activation kernel (no finalize launch)
 OVERLAP_WGRAD = True        # run a conv's weight gradient on a side stream, concurrently with its data gradient
@@ -321,7 +333,10 @@ class ConvBnAct(torch.autograd.Function):
         T = compute_dtype(x, weight)
         cout = weight.shape[0]
         acc_f = None
-        if training:
+        # deterministic mode: no float atomics anywhere -- the statistics come from the fixed-order two-level reduction
+        # (k_channel_reduce + finalize) instead of the conv epilogue, forward and backward
+        deterministic = training and deterministic_stats()
+        if training and not deterministic:
             acc_f = BnArena.current.take(cout) if BnArena.current is not None else None
             if acc_f is None:
                 acc_f = ops.bn_acc_new(cout, x.device)
@@ -339,33 +354,33 @@ class ConvBnAct(torch.autograd.Function):
             y = ops.conv_fwd(x, ops.stem_pack_weights(weight, T), None, cout, 1, 1, acc_f)
         elif depthwise:
             x = _as_nhwc(x, T)
-            y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9), acc_f if training else None)
+            y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9), acc_f)
         else:
             x = _as_nhwc(x, T)
             y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride, acc_f)
-        g32, b32 = _f32(gamma), _f32(beta)
+        # gamma / beta / running statistics go to the kernels in their own dtype (fp32; the low-precision parameter and
+        # buffer dtype under FSDP mixed precision, src/training/utils_train.py:84-89,146-153): no cast launches
         rm, rv = bufs
         if res is not None:
             res = _as_nhwc(res, T)
         acc_b = None
         if training:
-            rm32, rv32 = _f32(rm), _f32(rv)
-            if FOLD_BN_FINALIZE and BnArena.current is not None:
+            if FOLD_BN_FINALIZE and BnArena.current is not None and not deterministic:
                 acc_b = BnArena.current.take(cout)          # zeroed with the forward statistics; used by the backward
-            if FOLD_BN_FINALIZE:
-                out, mean, invstd, scale, shift = ops.bn_act_fwd_train(y, acc_f, g32, b32, rm32, rv32, momentum, eps, act, res, out)
+            if deterministic:
+                mean, invstd, scale, shift = ops.bn_train_stats(y, gamma, beta, rm, rv, momentum, eps)
+                out = ops.bn_act_fwd(y, scale, shift, act, res, out)
+            elif FOLD_BN_FINALIZE:
+                out, mean, invstd, scale, shift = ops.bn_act_fwd_train(y, acc_f, gamma, beta, rm, rv, momentum, eps, act, res, out)
             else:
                 count = y.shape[0] * y.shape[2] * y.shape[3]
-                mean, invstd, scale, shift = ops.bn_finalize_acc(acc_f, count, g32, b32, rm32, rv32, momentum, eps)
+                mean, invstd, scale, shift = ops.bn_finalize_acc(acc_f, count, gamma, beta, rm, rv, momentum, eps)
                 out = ops.bn_act_fwd(y, scale, shift, act, res, out)
-            if rm32 is not rm:
-                rm.copy_(rm32)
-                rv.copy_(rv32)
         else:
             mean = invstd = None
-            scale, shift = ops.bn_eval_coeffs(g32, b32, _f32(rm), _f32(rv), eps)
+            scale, shift = ops.bn_eval_coeffs(gamma, beta, rm, rv, eps)
             out = ops.bn_act_fwd(y, scale, shift, act, res, out)
-        saved = (scale, shift, mean, invstd, g32)
+        saved = (scale, shift, mean, invstd, gamma)
         ctx.acc_b = acc_b       # a slice of the arena other layers write to: kept off save_for_backward's version check
         ctx.cfg = (k, stride, depthwise, act, training, tuple(x.shape), res is not None, gamma.dtype, stem)
         ctx.stem_fused = stem_fused
@@ -378,12 +393,12 @@ class ConvBnAct(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors[:3]
         T = y.dtype
         dout = _as_nhwc(dout, T)
-        scale, shift, mean, invstd, g32 = ctx.saved_tensors[3:]
+        scale, shift, mean, invstd, gamma = ctx.saved_tensors[3:]
         acc_b = ctx.acc_b
         if training and acc_b is not None:
-            dy, dgamma, dbeta = ops.bn_act_bwd_train(dout, y, scale, shift, mean, invstd, g32, act, acc_b)
+            dy, dgamma, dbeta = ops.bn_act_bwd_train(dout, y, scale, shift, mean, invstd, gamma, act, acc_b)
         elif training:
-            dy, dgamma, dbeta = ops.bn_act_bwd(dout, y, scale, shift, mean, invstd, g32, act)
+            dy, dgamma, dbeta = ops.bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act)
         else:
             dy, dgamma, dbeta = ops.bn_act_bwd_eval(dout, y, scale, shift, act), None, None
         dx = dw = None
@@ -451,9 +466,7 @@ class ConvBnAct(torch.autograd.Function):
                 dx = dgrad()
             elif ctx.needs_input_grad[1]:
                 dw = ops.conv_wgrad(x, dy, k, stride, weight.dtype)
-        if dgamma is not None and ctx.needs_input_grad[2]:
-            dgamma, dbeta = dgamma.to(gdtype), dbeta.to(gdtype)
-        else:
+        if dgamma is None or not ctx.needs_input_grad[2]:      # (the kernels wrote them in the parameters' own dtype)
             dgamma = dbeta = None
         dres = dout if (has_res and ctx.needs_input_grad[4]) else None
         if has_res and ctx.res_link is not None and not ctx.res_link.fan:

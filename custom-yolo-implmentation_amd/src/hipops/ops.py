@@ -251,7 +251,8 @@ def bn_finalize_acc(acc, count, gamma, beta, running_mean, running_var, momentum
     coef = _f32(4 * c, gamma.device)
     mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
     lib.call("yolo_bn_finalize_acc", _p(acc), count, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-             float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), _stream(gamma))
+             float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), *_pb_dt(gamma, beta, running_mean, running_var),
+             _stream(gamma))
     return mean, invstd, scale, shift
 
 
@@ -265,7 +266,7 @@ def bn_act_fwd_train(y, acc, gamma, beta, running_mean, running_var, momentum, e
     ldr = geom(res)[4] if res is not None else 0
     lib.call("yolo_bn_act_fwd_train", _p(y), ld, _p(acc), n * h * w, _p(gamma), _p(beta), _p(running_mean),
              _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), _p(res), ldr, _p(out),
-             geom(out)[4], n * h * w, c, int(act), dt(y), _stream(y))
+             geom(out)[4], n * h * w, c, int(act), dt(y), *_pb_dt(gamma, beta, running_mean, running_var), _stream(y))
     return out, mean, invstd, scale, shift
 
 
@@ -278,10 +279,10 @@ def bn_act_bwd_train(dout, y, scale, shift, mean, invstd, gamma, act, acc):
     npix = n * h * w
     st = _stream(y)
     lib.call("yolo_bn_bwd_reduce_acc", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), npix, c, int(act), dt(y), _p(acc), st)
-    dgamma, dbeta = _f32(c, y.device), _f32(c, y.device)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)        # in the parameter's own dtype
     dy = new_nhwc(n, c, h, w, y.dtype, y.device)
     lib.call("yolo_bn_act_bwd_apply_train", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), _p(gamma), _p(mean), _p(invstd),
-             _p(acc), npix, _p(dgamma), _p(dbeta), _p(dy), c, npix, c, int(act), dt(y), st)
+             _p(acc), npix, _p(dgamma), _p(dbeta), _p(dy), c, npix, c, int(act), dt(y), dt(gamma), st)
     return dy, dgamma, dbeta
 
 
@@ -424,6 +425,17 @@ def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+def _pb_dt(gamma, beta, running_mean, running_var):
+    """(pdtype, bdtype) of a BatchNorm's parameters and buffers: the kernels read / write them in their own element type
+    (fp32 normally; FSDP mixed precision hands over low-precision parameters and buffers: no cast launches)."""
+    if beta.dtype != gamma.dtype or (running_mean is not None and running_var.dtype != running_mean.dtype):
+        raise RuntimeError("BatchNorm: gamma / beta (and running_mean / running_var) must share a dtype")
+    for t in (gamma, beta, running_mean, running_var):
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("BatchNorm: parameters and buffers must be contiguous")
+    return dt(gamma), dt(running_mean) if running_mean is not None else lib.F32
+
+
 def bn_train_stats(y, gamma, beta, running_mean, running_var, momentum, eps):
     """Batch statistics of y; updates the running buffers in place; -> (mean, invstd, scale, shift)."""
     n, c, h, w, ld = geom(y)
@@ -435,7 +447,7 @@ def bn_train_stats(y, gamma, beta, running_mean, running_var, momentum, eps):
     coef = _f32(4 * c, y.device)
     mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
     lib.call("yolo_bn_finalize", _p(part), nblk, npix, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-             float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), st)
+             float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), *_pb_dt(gamma, beta, running_mean, running_var), st)
     return mean, invstd, scale, shift
 
 
@@ -443,7 +455,7 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     c = gamma.numel()
     coef = _f32(2 * c, gamma.device)
     lib.call("yolo_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), c,
-             _p(coef[:c]), _p(coef[c:]), _stream(gamma))
+             _p(coef[:c]), _p(coef[c:]), *_pb_dt(gamma, beta, running_mean, running_var), _stream(gamma))
     return coef[:c], coef[c:]
 
 
@@ -468,9 +480,9 @@ def bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act):
              int(act), dt(y), _p(part), nblk, st)
     # dgamma / dbeta are returned to autograd: standalone tensors (a slice of a bigger buffer cannot be taken
     # over by AccumulateGrad and would be cloned with an extra copy kernel per parameter)
-    dgamma, dbeta, coef = _f32(c, y.device), _f32(c, y.device), _f32(3 * c, y.device)
+    dgamma, dbeta, coef = torch.empty_like(gamma), torch.empty_like(gamma), _f32(3 * c, y.device)
     lib.call("yolo_bn_bwd_finalize", _p(part), nblk, npix, c, _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta),
-             _p(coef), st)
+             _p(coef), dt(gamma), st)
     dy = new_nhwc(n, c, h, w, y.dtype, y.device)
     lib.call("yolo_bn_act_bwd_apply", _p(dout), ldd, _p(y), ldy, _p(scale), _p(shift), _p(mean), _p(invstd), _p(coef),
              _p(dy), c, npix, c, int(act), dt(y), st)

@@ -179,6 +179,12 @@ class TrainStepRunner:
             # the loss tensor is the fused loss node's own output: the seed of backward() (ones) reaches it unchanged
             F_.UNIT_LOSS_SEED = type(loss.grad_fn).__name__ == "DflQflLossBackward" and os.environ.get("YOLO_UNIT_SEED", "1") == "1"
             loss.backward()
+        except BaseException:
+            # stage B will not run: the lazy-join flag must not leak into a later plain backward (AccumulateGrad would
+            # add to / clone a gradient the side stream has not written yet)
+            F_.LAZY_WGRAD_JOIN = False
+            self._cut = None
+            raise
         finally:
             F_.UNIT_LOSS_SEED = False
             if self.staged:

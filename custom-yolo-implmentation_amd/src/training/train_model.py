@@ -53,12 +53,17 @@ def _make_scaler(precision, distributed_mode, device, rank):
 class CapturedTraining:
     """Training batches go through `TrainStepRunner`: the step captured once as hipGraphs on static image / target buffers
     that every batch refills (12.5 instead of 18 ms per step on preset s, where the eager loop is bound by the host's
-    launch rate).  The default in ddp mode on the GPU (`train(captured_step=None)`); `captured_step=False` or the config key
-    `training.captured_step: false` keeps the reference's eager loop.
+    launch rate).  The default in ddp mode on ONE GPU (`train(captured_step=None)`); with more than one rank it is opt-in
+    (`captured_step=True` / config key `training.captured_step: true`) until a multi-GPU run has verified it on hardware --
+    the default there is the reference's eager loop under torch's DistributedDataParallel reducer.  `captured_step=False`
+    keeps the eager loop everywhere.
 
     A DistributedDataParallel-wrapped model is stepped through its `.module`: the runner averages the gradients itself
-    (two flat buckets, all-reduced beside the backbone's backward: src/training/graph_step.py) -- same mean-over-ranks
-    result as the wrapper's reducer, whose hooks stay idle because the wrapper's own forward is not called.  (Capturing
+    (two flat buckets, all-reduced beside the backbone's backward: src/training/graph_step.py) in the gradients' own
+    dtype (fp32, like the wrapper's reducer: same mean over ranks); `grad_compress="bf16"` (config key
+    `training.ddp.grad_compress`) exchanges bf16 buckets instead, DDP's `bf16_compress_hook` -- a deviation of about
+    2^-8 relative per element from the reference, never the default.  The wrapper's hooks stay idle because its own
+    forward is not called.  (Capturing
     the WRAPPER's forward also works once its logger has stopped sampling, i.e. after 11 eager iterations --
     tools/capture_probe.py, profiles/r2_capture_probe.log -- but then RCCL kernels sit inside the graph; the eager
     collectives between graphs are the conservative choice.)  DDP re-broadcasts the BatchNorm buffers from rank 0 before
@@ -70,12 +75,15 @@ class CapturedTraining:
     group): all ranks replay or all ranks step eagerly, with the same buckets and reduction either way.  Needs a
     capturable optimizer and no GradScaler (bf16 / fp32)."""
 
-    def __init__(self, model, criterion, optimizer, precision):
+    def __init__(self, model, criterion, optimizer, precision, grad_compress=None):
         import torch.distributed as dist
         from torch.nn.parallel import DistributedDataParallel as DDP
         self.wrapper = model
         self.inner = model.module if isinstance(model, DDP) else model
         self.criterion, self.optimizer, self.precision = criterion, optimizer, precision
+        if grad_compress not in (None, "", "none", "bf16", "bfloat16"):
+            raise ValueError(f"grad_compress: expected 'bf16' or nothing, got {grad_compress!r}")
+        self.comm_dtype = torch.bfloat16 if grad_compress in ("bf16", "bfloat16") else None
         self.runner, self.dirty, self.captured = None, False, False
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.flag_group = None
@@ -104,7 +112,7 @@ class CapturedTraining:
             return None
         if self.runner is None:
             self.runner = TrainStepRunner(self.inner, self.criterion, self.optimizer, self.precision, use_graph=True,
-                                          grad_comm_dtype=torch.bfloat16 if self.precision == "bfloat16" else None)
+                                          grad_comm_dtype=self.comm_dtype)
         if not self.captured:
             cap = 128 * len(boxes)
             fits = sum(int(b.shape[0]) if b.numel() else 0 for b in boxes) <= cap
@@ -192,13 +200,17 @@ def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimi
 def train(model, train_loader, val_loader, optimizer, scheduler, criterion, initial_epoch, num_epochs, device,
           num_classes=171, rank=0, use_wandb=False, wandb_instance=None, log_interval=10,
           checkpoint_dir="experiments/checkpoints", iou_threshold=0.5, conf_threshold=0.25, distributed_mode="ddp",
-          precision="float32", captured_step=None):
-    """`captured_step`: None (default) = the captured step wherever it applies (ddp mode on the GPU, bf16 / fp32, plain
-    parameters, capturable optimizer), False = the reference's eager loop, True = as None."""
+          precision="float32", captured_step=None, grad_compress=None):
+    """`captured_step`: None (default) = the captured step where it applies AND has been verified on hardware (ddp mode on
+    one GPU, plain parameters, capturable optimizer), True = also with more than one rank, False = the reference's eager
+    loop.  `grad_compress`: None = fp32 gradient exchange (the reference's), "bf16" = bf16 buckets in the captured step."""
     use_amp = precision in ("float16", "bfloat16")
     scaler = _make_scaler(precision, distributed_mode, device, rank) if use_amp else None
-    captured = CapturedTraining(model, criterion, optimizer, precision) \
-        if (captured_step is not False and device != "cpu" and distributed_mode == "ddp" and scaler is None) else None
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    want_captured = captured_step is True or (captured_step is None and world == 1)
+    captured = CapturedTraining(model, criterion, optimizer, precision, grad_compress=grad_compress) \
+        if (want_captured and device != "cpu" and distributed_mode == "ddp" and scaler is None) else None
     if captured is not None and not captured.usable:
         captured = None
     autocast_kw = dict(device_type="cpu" if device == "cpu" else "cuda",

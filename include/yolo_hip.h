@@ -12,8 +12,14 @@
  *     concat buffers are passed as base+offset with the buffer's ld); dtype codes below; parameters,
  *     statistics and reductions are fp32
  *   - return 0 on success, a hipError_t value or YOLO_ERR_* otherwise; never aborts
- *   - re-entrant, no global mutable state; the caller's stream is explicit (autograd's backward thread
- *     and DDP hooks call in concurrently with the main thread)
+ *   - re-entrant; the caller's stream is explicit (autograd's backward thread and DDP hooks call in
+ *     concurrently with the main thread).  Process-wide state is limited to (a) once-initialised, read-only
+ *     caches (per-device kernel attributes, tile plans) and (b) TEST / TUNING overrides that no product
+ *     code path sets: yolo_conv_tune_set / yolo_wgrad_tune_set (forced tile variants in
+ *     tests/test_gpu_conv_variants.py, tools/) and the environment switches read once at first use
+ *     (YOLO_CONV_TUNE, YOLO_WG_TUNE, YOLO_WG_BLOCKS, YOLO_WG_SCALE, YOLO_WG_FLOOR, YOLO_WG_XCD,
+ *     YOLO_DGRAD2_PATCH, YOLO_ATTN_FUSED: A/B measurement only).  With none of them set, results depend
+ *     on the arguments alone
  *
  * One prototype per line, `int|long|size_t name(args);` -- the Python loader parses this file.
  */
@@ -111,23 +117,26 @@ int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int
 int yolo_dw_wgrad_nslab(int N, int H);
 int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* partial, int N, int H, int W, int C, int dtype, hipStream_t st);
 
-/* ---- BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU/Identity + residual add (model_blocks.py:28-34,62,223-224) */
+/* ---- BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU/Identity + residual add (model_blocks.py:28-34,62,223-224)
+ * pdtype = element type of gamma / beta (and of dgamma / dbeta), bdtype = element type of the running statistics:
+ * YOLO_F32 under DDP / autocast; under FSDP mixed precision the reference casts parameters and BatchNorm buffers to
+ * the low-precision dtype (src/training/utils_train.py:84-89,146-153) and they are read / written as they are. */
 int yolo_reduce_nblk(long npix, int C);
 int yolo_bn_stats(const void* y, int ldy, long npix, int C, int dtype, float* partial, int nblk, hipStream_t st);
-int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
-int yolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C, float* scale, float* shift, hipStream_t st);
+int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const void* gamma, const void* beta, void* running_mean, void* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int pdtype, int bdtype, hipStream_t st);
+int yolo_bn_eval_coeffs(const void* gamma, const void* beta, const void* running_mean, const void* running_var, float eps, int C, float* scale, float* shift, int pdtype, int bdtype, hipStream_t st);
 int yolo_sum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st);
 int yolo_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype, hipStream_t st);
 int yolo_bn_act_bwd_reduce(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, long npix, int C, int act, int dtype, float* partial, int nblk, hipStream_t st);
-int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st);
+int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, const void* gamma, const float* mean, const float* invstd, void* dgamma, void* dbeta, float* coef, int pdtype, hipStream_t st);
 int yolo_bn_act_bwd_apply(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd, const float* coef, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
 /* accumulator form used by the training path: sums live in a caller-zeroed fp32 acc[8][2][C]; no finalize launches */
 int yolo_bn_acc_elems(int C);
 int yolo_bn_stats_acc(const void* y, int ldy, long npix, int C, int dtype, float* acc, hipStream_t st);
-int yolo_bn_finalize_acc(const float* acc, long count, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
-int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype, hipStream_t st);
+int yolo_bn_finalize_acc(const float* acc, long count, int C, const void* gamma, const void* beta, void* running_mean, void* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int pdtype, int bdtype, hipStream_t st);
+int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, const void* gamma, const void* beta, void* running_mean, void* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, const void* res, int ldres, void* out, int ldout, long npix, int C, int act, int dtype, int pdtype, int bdtype, hipStream_t st);
 int yolo_bn_bwd_reduce_acc(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, long npix, int C, int act, int dtype, float* acc, hipStream_t st);
-int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const float* gamma, const float* mean, const float* invstd, const float* acc, long count, float* dgamma, float* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype, hipStream_t st);
+int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ldy, const float* scale, const float* shift, const void* gamma, const float* mean, const float* invstd, const float* acc, long count, void* dgamma, void* dbeta, void* dy, int lddy, long npix, int C, int act, int dtype, int pdtype, hipStream_t st);
 
 /* ---- SPPF max pool (model_blocks.py:150-156) and nearest x2 upsample (neck.py:31,41-42) */
 int yolo_maxpool5_fwd(const void* x, int ldx, void* out, int ldo, uint8_t* idx, int N, int H, int W, int C, int dtype, hipStream_t st);

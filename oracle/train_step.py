@@ -115,10 +115,11 @@ def config5_nms_tensor(bs=8, nc=80, m=33600, seed=0):
     return pred
 
 
-def time_cpu_nms(images=2):
-    """ms / image of the reference's non_max_suppression path (Python loop + greedy NMS) restated on the host, config-5 tensor."""
+def time_cpu_nms(images=2, pred=None):
+    """ms / image of the reference's non_max_suppression path (Python loop + greedy NMS) restated on the host, config-5 tensor
+    (`pred`: the caller's tensor, so the device leg and this one see the same input)."""
     from . import postproc as opost
-    pred = config5_nms_tensor(bs=images).half().float()
+    pred = (config5_nms_tensor(bs=images) if pred is None else pred[:images]).half().float()
     t0 = time.perf_counter()
     out = opost.non_max_suppression(pred.clone(), conf_thres=0.25, iou_thres=0.45, nc=80)
     dt = time.perf_counter() - t0

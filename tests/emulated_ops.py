@@ -230,8 +230,8 @@ def bn_act_bwd(dout, y, scale, shift, mean, invstd, gamma, act):
     m = yf.numel() // yf.shape[1]
     dbeta = dz.sum((0, 2, 3))
     dgamma = (dz * yh).sum((0, 2, 3))
-    dy = v(gamma * invstd) * (dz - v(dbeta) / m - yh * v(dgamma) / m)
-    return _nhwc(dy.to(y.dtype)), dgamma, dbeta
+    dy = v(gamma.float() * invstd) * (dz - v(dbeta) / m - yh * v(dgamma) / m)
+    return _nhwc(dy.to(y.dtype)), dgamma.to(gamma.dtype), dbeta.to(gamma.dtype)     # like the kernels: the parameter's dtype
 
 
 def bn_act_bwd_eval(dout, y, scale, shift, act):

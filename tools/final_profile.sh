@@ -5,7 +5,7 @@ set -o pipefail
 tag=${1:-final}
 out=gpurun_out/$tag
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $out/stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra > $out/fetch.log 2>&1 || exit 1

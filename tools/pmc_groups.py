@@ -32,10 +32,11 @@ fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, nw = load(sys.argv[2], "WRITE_SIZE")
 print("| kernel group | launches / step | FETCH_SIZE corrected (GB / step) | WRITE_SIZE (GB / step) | total | MB / launch |")
 print("|---|---|---|---|---|---|")
+tf = tw = 0.0
 for name, _, corr in GROUPS:
     if not nf[name]:
         continue
     f, w, n = fetch[name] * corr * 1024 / 1e9 / steps, write[name] * 1024 / 1e9 / steps, nf[name] / steps
     print(f"| {name} | {n:.0f} | {f:.2f} | {w:.2f} | {f + w:.2f} | {(f + w) * 1e3 / n:.1f} |")
-    tf, tw = (locals().get("tf", 0.0) + f), (locals().get("tw", 0.0) + w)
+    tf, tw = tf + f, tw + w
 print(f"| **all kernels** | | {tf:.2f} | {tw:.2f} | {tf + tw:.2f} | |")
