@@ -10,12 +10,27 @@ src/training/train_model.py:247-253).
   autograd every eager step, so the table is rebuilt when a pointer changed; inside a graph capture the pointers are
   final but an upload cannot be captured safely, so `step()` only records the launch and `finish_capture()` -- called
   by TrainStepRunner after the capture -- uploads the table once.
+* FSDP2 (`fully_shard`) parameters are DTensors: the kernel updates each rank's LOCAL shard (a persistent view of the
+  wrapper's sharded storage) from the local shard of the reduce-scattered gradient; the moments are DTensors with the
+  parameter's placement, so `torch.distributed.checkpoint` gathers / scatters the optimizer state like torch.optim.AdamW's.
+  There GradScaler unscales the gradients itself (`_step_supports_amp_scaling` off: ShardedGradScaler must all-reduce
+  found_inf across ranks before anyone steps).
 There is no CPU path: parameters must live on the GPU (like every op of this package).
 """
 import torch
 
 from src.hipops import lib
 from src.hipops.ops import _p, _stream, dt
+
+try:
+    from torch.distributed.tensor import DTensor
+except ImportError:  # pragma: no cover
+    DTensor = ()
+
+
+def _loc(t):
+    """The tensor the kernel touches: a DTensor's local shard, else the tensor itself."""
+    return t._local_tensor if isinstance(t, DTensor) else t
 
 
 class HipAdamW(torch.optim.Optimizer):
@@ -27,6 +42,8 @@ class HipAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                         foreach=None, capturable=True, differentiable=False, fused=True)
         super().__init__(params, defaults)
+        if any(isinstance(p, DTensor) for g in self.param_groups for p in g["params"]):
+            self._step_supports_amp_scaling = False     # sharded: the scaler unscales and agrees on found_inf across ranks
         self._plans = {}                    # group index -> dict(ptrs, jobs_dev, njobs, nchunks, hyper, hyper_host, step)
         self._pending = []                  # (jobs_dev, pinned host table) awaiting upload after a capture
         # grad_scale / found_inf are NOT pre-defined: GradScaler.step multiplies an existing grad_scale attribute in,
@@ -44,8 +61,12 @@ class HipAdamW(torch.optim.Optimizer):
             st = self.state[p]
             if "exp_avg" not in st:
                 st["step"] = plan["step"]                           # one shared device counter per group
-                st["exp_avg"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
-                st["exp_avg_sq"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+                if isinstance(p, DTensor):                           # same mesh / placement as the parameter
+                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
+                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
+                else:
+                    st["exp_avg"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+                    st["exp_avg_sq"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
             elif st["step"] is not plan["step"]:                    # after load_state_dict: adopt the loaded count
                 plan["step"].copy_(torch.as_tensor(st["step"], dtype=torch.float32).reshape(()))
                 st["step"] = plan["step"]
@@ -102,7 +123,7 @@ class HipAdamW(torch.optim.Optimizer):
                 raise RuntimeError("HipAdamW implements plain AdamW (amsgrad=False, maximize=False)")
             plan = self._init_state(group, gi)
             capturing = torch.cuda.is_current_stream_capturing()
-            ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+            ptrs = tuple((_loc(p).data_ptr(), _loc(p.grad).data_ptr(), _loc(p).numel()) for p in params)
             if plan["ptrs"] != ptrs:
                 old = plan["ptrs"]
                 if (not capturing and old is not None and len(old) == len(ptrs) and plan["host"] is not None
@@ -135,7 +156,7 @@ class HipAdamW(torch.optim.Optimizer):
                 raise RuntimeError("HipAdamW: run one eager step (or sync_hyper()) before capturing a graph")
             lib.call("yolo_adamw_step", _p(plan["jobs_dev"]), plan["njobs"], plan["nchunks"], _p(plan["hyper"]),
                      _p(plan["step"]), _p(getattr(self, "grad_scale", None)), _p(getattr(self, "found_inf", None)),
-                     _stream(params[0]))      # GradScaler sets the two attributes around step() and deletes them after
+                     _stream(_loc(params[0])))      # GradScaler sets the two attributes around step() and deletes them after
         return loss
 
     def _build(self, plan, params, capturing):
@@ -146,14 +167,16 @@ class HipAdamW(torch.optim.Optimizer):
                 raise RuntimeError("HipAdamW: run one eager step before capturing a graph (host/device tables are "
                                    "allocated there)")
             plan["host"] = torch.zeros(n * jb, dtype=torch.uint8).pin_memory()
-            plan["jobs_dev"] = torch.empty(n * jb, dtype=torch.uint8, device=params[0].device)
+            plan["jobs_dev"] = torch.empty(n * jb, dtype=torch.uint8, device=_loc(params[0]).device)
         host = plan["host"]
         for i, p in enumerate(params):
-            if not (p.is_contiguous() and p.grad.is_contiguous()):
-                raise RuntimeError("HipAdamW needs contiguous parameters and gradients")
             st = self.state[p]
-            lib.call("yolo_adamw_job_fill", host.data_ptr(), i, _p(p), dt(p), _p(p.grad), dt(p.grad), _p(st["exp_avg"]),
-                     _p(st["exp_avg_sq"]), p.numel())
+            w, g, m1, m2 = _loc(p), _loc(p.grad), _loc(st["exp_avg"]), _loc(st["exp_avg_sq"])
+            if not (w.is_contiguous() and g.is_contiguous() and m1.is_contiguous() and m2.is_contiguous()):
+                raise RuntimeError("HipAdamW needs contiguous parameters, gradients and moments")
+            if not (g.numel() == m1.numel() == m2.numel() == w.numel()):
+                raise RuntimeError("HipAdamW: gradient / moment shards do not match the parameter's local shard")
+            lib.call("yolo_adamw_job_fill", host.data_ptr(), i, _p(w), dt(w), _p(g), dt(g), _p(m1), _p(m2), w.numel())
         plan["nchunks"] = lib.query("yolo_adamw_jobs_finalize", host.data_ptr(), n)
         plan["njobs"] = n
         if capturing:

@@ -24,15 +24,16 @@ _LOWP = ("bfloat16", "float16")
 
 def get_optimizer(model: nn.Module, lr: float, weight_decay: float, patience: int, factor: float
                   ) -> Tuple[optim.Optimizer, optim.lr_scheduler.ReduceLROnPlateau]:
-    """AdamW + ReduceLROnPlateau (reference :20-36).  Plain GPU parameters (single GPU, DDP) get the one-launch
-    `HipAdamW` (same update rule, state names and scheduler / GradScaler / checkpoint behaviour as torch.optim.AdamW,
-    whose default eager form issues several small kernels per parameter); sharded parameters (FSDP flat parameters,
-    FSDP2 DTensors) keep torch.optim.AdamW."""
+    """AdamW + ReduceLROnPlateau (reference :20-36).  GPU parameters get the one-launch `HipAdamW` (same update rule,
+    state names and scheduler / GradScaler / checkpoint behaviour as torch.optim.AdamW, whose default eager form issues
+    several small kernels per parameter): plain parameters (single GPU, DDP) and FSDP2's DTensor parameters, whose local
+    shards it updates in place.  FSDP1 (use_orig_params=True) exposes plain-looking nn.Parameters that are views of its
+    flat shards, re-pointed every step: it keeps torch.optim.AdamW, and so does anything on the CPU."""
+    from torch.distributed.tensor import DTensor
     params = list(model.parameters())
-    # FSDP1 (use_orig_params=True) exposes plain-looking nn.Parameters that are views of its flat shards, re-pointed
-    # every step: sharded models keep torch.optim.AdamW
-    plain = params and not _is_sharded(model) and all(type(p) is nn.Parameter and p.is_cuda for p in params)
-    if plain:
+    fsdp1 = isinstance(model, FSDP) or any(isinstance(m, FSDP) for m in model.modules())
+    ok = lambda p: (type(p) is nn.Parameter and p.is_cuda) or (isinstance(p, DTensor) and p._local_tensor.is_cuda)
+    if params and not fsdp1 and all(ok(p) for p in params):
         from src.training.fused_adamw import HipAdamW
         opt = HipAdamW(params, lr=lr, weight_decay=weight_decay)
     else:

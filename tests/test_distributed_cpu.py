@@ -121,3 +121,104 @@ def test_single_process_wrappers_and_reduce_are_noops_without_a_group():
     sys.path.insert(0, os.path.join(HERE, "..", "custom-yolo-implmentation_amd"))
     from src.training.distributed_setup import reduce_value, reduce_values
     assert reduce_value(3.5) == 3.5 and reduce_values([1.0, 2.0]) == [1.0, 2.0]
+
+
+def _fsdp2_worker(rank, world, port, out, ckdir, precision):
+    """BASELINE config 4's wrapper on two ranks: `prepare_fsdp2_model` (fully_shard per C3K2 / SPPF / PSA + root, reference
+    src/training/utils_train.py:116-165) over the product Model with its HIP leaves swapped for the torch stand-ins."""
+    for p in (HERE, os.path.join(HERE, ".."), os.path.join(HERE, "..", "custom-yolo-implmentation_amd")):
+        sys.path.insert(0, os.path.abspath(p))
+    import emulated_ops
+    emulated_ops.install_plain()
+    from oracle.params import det_fill_
+    from src.model.losses import YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.utils_train import (checkpoint_states, get_optimizer, load_checkpoint, prepare_fsdp2_model,
+                                          save_checkpoint)
+
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    img, gts = _batch(rank)
+    crit = YoloDFLQFLoss(num_classes=4)
+    lowp = getattr(torch, precision) if precision != "float32" else None
+
+    def fresh():
+        m = Model(**TINY, num_classes=4)
+        det_fill_(m.state_dict(), 1)
+        return m.train()
+
+    def flat(grads):
+        return torch.cat([g.float().flatten() for g in grads])
+
+    # (1) what every rank computes alone under the wrapper's numeric contract: parameters AND BatchNorm buffers in the
+    # low-precision dtype, inputs cast, no autocast (reference :146-153, train_model.py:240-245)
+    m0 = fresh()
+    if lowp is not None:
+        m0 = m0.to(lowp)
+    p, a, s = m0(img if lowp is None else img.to(lowp))
+    crit(p, gts, a, s)[0].backward()
+    names = [k for k, q in m0.named_parameters() if q.grad is not None]
+    local = flat(q.grad for q in m0.parameters() if q.grad is not None)
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean = torch.stack(gathered).mean(0)
+
+    # (2) the wrapper: sharded parameters, all-gather before each group's forward / backward, reduce-scatter of the gradients
+    m1 = prepare_fsdp2_model(fresh(), 0, {"precision": precision}, world, "cpu")
+    from torch.distributed.tensor import DTensor
+    assert all(isinstance(q, DTensor) for q in m1.parameters())
+    sharded = sum(q.to_local().numel() for q in m1.parameters())
+    total = sum(q.numel() for q in m1.parameters())
+    p1, a, s = m1(img)
+    loss, _ = crit(p1, gts, a, s)
+    loss.backward()
+    grads = {k: q.grad.full_tensor() for k, q in m1.named_parameters() if q.grad is not None}
+    assert list(grads) == names
+    g1 = flat(grads[k] for k in names)
+    bufs_lowp = all(b.dtype == lowp for b in m1.buffers() if b.is_floating_point()) if lowp is not None else True
+
+    # (3) one optimizer step on the shards, then the checkpoint: gathered by a collective on both ranks, written by rank 0,
+    # loadable by a bare Model (the reference pickles DTensor shards, which nothing loads back: notebooks/04)
+    opt, _ = get_optimizer(m1, lr=1e-3, weight_decay=1e-4, patience=3, factor=0.5)
+    opt.step()
+    states = checkpoint_states(m1, opt)
+    if rank == 0:
+        save_checkpoint(m1, opt, 1, 0.5, checkpoint_dir=ckdir, states=states)
+    dist.barrier()
+    path = os.path.join(ckdir, "model_epoch_1.pth")
+    full = {k: q.full_tensor().float() for k, q in m1.named_parameters()}
+    bare = Model(**TINY, num_classes=4)
+    bare.load_weights(path)
+    bare_err = max(float((dict(bare.named_parameters())[k].float() - v).abs().max()) for k, v in full.items())
+    # ... and resumes a freshly wrapped model on both ranks
+    m2 = prepare_fsdp2_model(Model(**TINY, num_classes=4), 0, {"precision": precision}, world, "cpu")
+    opt2, _ = get_optimizer(m2, lr=1e-3, weight_decay=1e-4, patience=3, factor=0.5)
+    epoch = load_checkpoint(m2, opt2, path)
+    resume_err = max(float((q.full_tensor().float() - full[k]).abs().max()) for k, q in m2.named_parameters())
+
+    if rank == 0:
+        torch.save(dict(err=float((g1 - mean).abs().max()), scale=float(mean.abs().max()),
+                        differs=float((local - mean).abs().max()), sharded_frac=sharded / total, bufs_lowp=bufs_lowp,
+                        pred_dtype=str(p1.dtype), bare_err=bare_err, resume_err=resume_err, epoch=epoch,
+                        moved=float((flat(full.values()) - flat(dict(fresh().named_parameters())[k].detach() for k in full)).abs().max())),
+                   out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("precision", ["float32", "bfloat16"])
+def test_two_rank_gloo_fully_shard_gradients_and_checkpoint(tmp_path, precision):
+    """FSDP2 on two ranks: the unsharded gradients equal the mean of the ranks' local gradients (computed alone under the
+    same numeric contract), every parameter is sharded in half, a checkpoint gathered on the two ranks loads into a bare
+    Model and resumes a freshly wrapped one."""
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_fsdp2_worker, args=(2, _free_port(), out, str(tmp_path), precision), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["differs"] > 1e-3 * r["scale"]                          # the ranks really had different gradients
+    tol = 1e-5 if precision == "float32" else 2e-2                   # bf16: one rounding of the mean per element
+    assert r["err"] <= tol * r["scale"], r
+    assert 0.45 < r["sharded_frac"] < 0.62, r                        # every rank holds about half of every parameter
+    assert r["bufs_lowp"] and r["pred_dtype"] == "torch." + precision
+    assert r["bare_err"] == 0.0 and r["resume_err"] == 0.0 and r["epoch"] == 1
+    assert r["moved"] > 0                                            # the optimizer stepped on the shards

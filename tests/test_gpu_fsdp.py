@@ -1,0 +1,165 @@
+"""-m gpu: BASELINE config 4's wrappers.  `prepare_fsdp2_model` (fully_shard per C3K2 / SPPF / PSA + root, reference
+src/training/utils_train.py:116-165) and `prepare_fsdp_model` (FSDP1, :58-114) over the HIP-backed model on a one-rank RCCL
+group: predictions, EVERY parameter gradient and the BatchNorm running statistics against
+
+  (a) the fp32 CPU oracle, and
+  (b) the oracle run under the wrappers' own numeric contract -- parameters AND BatchNorm buffers cast to the low-precision
+      dtype, inputs cast, NO autocast (reference :84-89,146-153; src/training/train_model.py:240-245) -- which is what the
+      reference's FSDP modes compute on the CPU.
+
+Two ranks of the same wrapper run on gloo in tests/test_distributed_cpu.py (no second GPU on this pool)."""
+import os
+
+import pytest
+import torch
+
+from oracle import blocks as ob
+from oracle.params import ParamStore, det_fill_
+from test_gpu_model import _cotangent, _grad_errors, _rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    from src.training.distributed_setup import cleanup_distribute_mode, init_distributed_mode
+    yield init_distributed_mode("cuda")
+    cleanup_distribute_mode()
+
+
+class CastStore(ParamStore):
+    """The oracle's parameters as the FSDP mixed-precision policy hands them to the modules: fp32 masters (they receive
+    the gradients), every floating-point parameter and buffer cast to `dtype` before use."""
+
+    def __init__(self, seed, dtype):
+        super().__init__(seed, requires_grad=True)
+        self.dtype, self.cast = dtype, {}
+
+    def want(self, key, shape):
+        if key not in self.cast:
+            t = super().want(key, shape)
+            self.cast[key] = t.to(self.dtype) if t.is_floating_point() else t
+        return self.cast[key]
+
+
+def _canon(name):
+    from src.training.utils_train import canonical_state_dict
+    return next(iter(canonical_state_dict({name: 0})))
+
+
+def _full(t):
+    return t.full_tensor() if hasattr(t, "full_tensor") else t
+
+
+CASES = [("fsdp2", "n", "float32"), ("fsdp2", "n", "bfloat16"), ("fsdp2", "l", "float32"), ("fsdp2", "l", "bfloat16"),
+         ("fsdp2", "n", "float16"), ("fsdp", "n", "float32"), ("fsdp", "n", "bfloat16"), ("fsdp", "l", "bfloat16")]
+
+
+@pytest.mark.parametrize("wrapper,preset,precision", CASES)
+def test_sharded_wrappers_predictions_and_all_gradients(pg, wrapper, preset, precision):
+    from src.model.model_builder import Model
+    from src.training.utils_train import prepare_fsdp2_model, prepare_fsdp_model
+    rank, world, gpu = pg
+    cfg, res = ob.PRESETS[preset], 320
+    model = Model(**cfg, num_classes=80)
+    det_fill_(model.state_dict(), 2)
+    wrap = prepare_fsdp2_model if wrapper == "fsdp2" else prepare_fsdp_model
+    model = wrap(model=model, device_id=gpu, config={"precision": precision, "sharding_strategy": "FULL_SHARD",
+                                                      "auto_wrap_policy_min_params": 20000}, world_size=world, device="cuda")
+    model.train()
+    img = torch.randn(2, 3, res, res, generator=torch.Generator().manual_seed(9))
+    lowp = None if precision == "float32" else getattr(torch, precision)
+    preds, a, s = model(img.cuda())                        # no autocast in the FSDP modes (reference train_model.py:240-245)
+    assert preds.dtype == (lowp or torch.float32) and a.dtype == preds.dtype
+    ct = _cotangent(tuple(preds.shape), 4)
+    preds.backward(ct.to(preds.dtype).cuda())
+    grads = {_canon(k): _full(p.grad) for k, p in model.named_parameters() if p.grad is not None}
+    assert all(g.dtype == torch.float32 for g in grads.values())          # the sharded masters and their gradients stay fp32
+    bufs = {_canon(k): b for k, b in model.named_buffers()}
+
+    ps = ParamStore(2, requires_grad=True)
+    p_ref, _, _ = ob.model_forward(ps, img, cfg["width"], cfg["depth"], cfg["csp"], 80, training=True)
+    p_ref.backward(ct)
+    e_p = _rel(preds, p_ref)
+    hip = _grad_errors(grads, ps)
+    assert len(hip) >= (500 if preset == "l" else 240)
+    med = sorted(r for _, r in hip.values())[len(hip) // 2]
+    msg = (f"\n[{wrapper} {preset}@{res} {precision}] preds max-rel {e_p:.2e}; {len(hip)} gradient tensors: min cosine "
+           f"{min(c for c, _ in hip.values()):.5f}, median rel-L2 {med:.4f}, max rel-L2 {max(r for _, r in hip.values()):.4f}")
+    rv_key = "net.p1.0.norm.running_var"
+    if lowp is None:
+        print(msg)
+        assert e_p < 1e-3
+        bad = [(k, c, r) for k, (c, r) in hip.items() if c < 0.99999 or r > 2e-3]
+        assert not bad, bad[:5]
+        assert _rel(bufs[rv_key], ps[rv_key]) < 1e-4 and bufs[rv_key].dtype == torch.float32
+        return
+    # the wrappers' contract on the CPU: low-precision parameters and buffers, no autocast
+    cs = CastStore(2, lowp)
+    p16, a16, _ = ob.model_forward(cs, img.to(lowp), cfg["width"], cfg["depth"], cfg["csp"], 80, training=True)
+    assert p16.dtype == lowp and a16.dtype == lowp
+    p16.backward(ct.to(lowp))
+    cpu = _grad_errors({k: v.grad for k, v in cs.items() if getattr(v, "grad", None) is not None}, ps)
+    med16 = sorted(r for _, r in cpu.values())[len(cpu) // 2]
+    print(msg + f" | CPU under the same contract: preds {_rel(p16, p_ref):.2e}, min cosine {min(c for c, _ in cpu.values()):.5f}, "
+          f"median rel-L2 {med16:.4f}, max rel-L2 {max(r for _, r in cpu.values()):.4f}")
+    assert e_p < 2 * _rel(p16, p_ref) + 1e-2
+    bad = [(k, hip[k], cpu[k]) for k in hip if hip[k][1] > 2 * cpu[k][1] + 0.05]
+    assert not bad, f"{len(bad)} tensors further from fp32 than twice the CPU path under the same contract: {bad[:5]}"
+    assert med <= 1.25 * med16 + 0.01, (med, med16)
+    # BatchNorm buffers follow the parameter dtype (reference :150-153) and hold the same running statistics
+    assert all(b.dtype == lowp for b in bufs.values() if b.is_floating_point())
+    eps = 2.0 ** -7 if lowp == torch.bfloat16 else 2.0 ** -10
+    for k in (rv_key, "net.p1.0.norm.running_mean", "head.box.0.0.norm.running_var"):
+        ref = cs.cast[k].float()
+        assert float((bufs[k].float().cpu() - ref).abs().max()) <= 2 * eps * float(ref.abs().max()) + 1e-3, k
+
+
+def test_fsdp2_step_uses_the_one_launch_optimizer_and_no_cast_kernels(pg):
+    """The sharded path's step: HipAdamW on the local shards (moments are DTensors with the parameter's placement) equals
+    torch.optim.AdamW on the same gradients, and a bf16 forward + backward under the wrapper launches no ATen cast of
+    BatchNorm parameters or buffers (the kernels read them as they are)."""
+    from torch.distributed.tensor import DTensor
+    from src.model.model_builder import Model
+    from src.training.fused_adamw import HipAdamW
+    from src.training.utils_train import get_optimizer, prepare_fsdp2_model
+    rank, world, gpu = pg
+    cfg = ob.PRESETS["n"]
+
+    def build():
+        m = Model(**cfg, num_classes=80)
+        det_fill_(m.state_dict(), 3)
+        return prepare_fsdp2_model(model=m, device_id=gpu, config={"precision": "bfloat16"}, world_size=world, device="cuda").train()
+
+    img = torch.randn(2, 3, 160, 160, generator=torch.Generator().manual_seed(3)).cuda()
+    m1, m2 = build(), build()
+    o1, _ = get_optimizer(m1, lr=1e-3, weight_decay=1e-2, patience=3, factor=0.5)
+    assert type(o1) is HipAdamW and not o1._step_supports_amp_scaling
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-3, weight_decay=1e-2)
+    for m in (m1, m2):
+        m(img)[0].float().square().mean().backward()
+    with torch.no_grad():                                   # identical gradients for both optimizers
+        for p1, p2 in zip(m1.parameters(), m2.parameters()):
+            if p1.grad is not None:
+                p2.grad._local_tensor.copy_(p1.grad._local_tensor)
+    o1.step()
+    o2.step()
+    for (k, p1), p2 in zip(m1.named_parameters(), m2.parameters()):
+        assert isinstance(p1, DTensor)
+        if p1.grad is None:
+            continue
+        st = o1.state[p1]
+        assert isinstance(st["exp_avg"], DTensor) and st["exp_avg"].placements == p1.placements
+        a, b = p1.full_tensor(), p2.full_tensor()
+        assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(b.abs().max()), k
+
+    # no cast launches for gamma / beta / running statistics: count ATen copy kernels of a forward + backward
+    from torch.profiler import ProfilerActivity, profile
+    m1.zero_grad(set_to_none=True)
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        m1(img)[0].float().square().mean().backward()
+    n_bn = sum(1 for m in m1.modules() if type(m).__name__ == "Conv")
+    copies = sum(e.count for e in prof.key_averages() if e.key in ("aten::_to_copy", "aten::copy_"))
+    print(f"\n[fsdp2 bf16 step] {n_bn} Conv blocks, {copies} aten copy / cast calls in one forward + backward")
+    assert copies < 2 * n_bn, copies          # round 2: eight casts per block (gamma, beta, two buffers there and back, two gradients)

@@ -21,6 +21,7 @@ def pg():
 
 @pytest.mark.parametrize("mode,precision,captured", [("ddp", "bfloat16", False), ("ddp", "float32", False),
                                                      ("ddp", "float16", False), ("fsdp2", "bfloat16", False),
+                                                     ("fsdp2", "float16", False),
                                                      ("fsdp", "bfloat16", False), ("fsdp", "float32", False),
                                                      ("ddp", "bfloat16", True), ("ddp", "float32", True)])
 def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path):
@@ -40,8 +41,10 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path
     tr, va = get_data_loaders("/nonexistent/train", "/nonexistent/val", "", "", batch_size=4, is_test=True, device="cuda",
                               num_classes=80, res=160)
     opt, sched = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
-    if mode != "ddp":                       # sharded parameters keep torch.optim.AdamW (FSDP1's are views of its flat shards)
-        assert type(opt) is torch.optim.AdamW
+    from src.training.fused_adamw import HipAdamW
+    # FSDP1's parameters are views of its flat shards, re-pointed every step: torch.optim.AdamW; everything else (plain
+    # parameters, FSDP2's DTensor shards) steps in one launch
+    assert type(opt) is (torch.optim.AdamW if mode == "fsdp" else HipAdamW)
     before = [p.detach().float().clone() for p in model.parameters()][:3]
     train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched,
           criterion=YoloDFLQFLoss(num_classes=80), initial_epoch=0, num_epochs=1, device=gpu, num_classes=80, rank=rank,
