@@ -173,6 +173,55 @@ def measure_preset(preset, batch, res, nc, dev, steps, warmup):
                 final_loss=round(float(loss), 5))
 
 
+def measure_fsdp2(preset, batch, res, nc, dev, steps, warmup, precision="bfloat16"):
+    """BASELINE config 4's path per GPU: the model under `prepare_fsdp2_model` (fully_shard per C3K2 / SPPF / PSA + root,
+    bf16 parameters AND BatchNorm buffers, no autocast: reference src/training/utils_train.py:116-165) stepped by the
+    reference's loop body (src/training/train_model.py:234-253: zero_grad, forward, loss, backward, optimizer step) on a
+    one-rank RCCL group -- every all-gather / reduce-scatter is issued, over one rank.  Eager (FSDP2's hooks are host
+    code), so this is the host-bound figure of the sharded path; the unsharded captured step of the same model is
+    `preset_l_640_bf16_16img`."""
+    import socket
+    from src.model.losses import YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.utils_train import get_optimizer, prepare_fsdp2_model
+    own = not dist.is_initialized()
+    if own:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        model = Model(**PRESETS[preset], num_classes=nc)
+        model = prepare_fsdp2_model(model=model, device_id=dev.index, config={"precision": precision}, world_size=1, device="cuda").train()
+        opt, _ = get_optimizer(model, lr=1e-4, weight_decay=1e-4, patience=3, factor=0.5)
+        crit = YoloDFLQFLoss(num_classes=nc)
+        img, gts = synthetic_batch(batch, res, nc, 4321, dev)
+
+        def step():
+            opt.zero_grad()
+            preds, anchors, strides = model(img)
+            loss, ld = crit(preds, gts, anchors, strides)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        groups = sum(1 for m in model.modules() if type(m).__name__.startswith("FSDP"))
+        return dict(images_per_s=round(batch * steps / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), steps=steps, batch=batch,
+                    final_loss=round(float(loss), 5), wrapper="prepare_fsdp2_model", fsdp_groups=groups, world=1, eager=True,
+                    optimizer=type(opt).__name__, param_dtype=precision)
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def config5_nms_tensor(bs=8, nc=80, m=33600, seed=0):
     """BASELINE config 5's NMS / IoU stress tensor: (bs, 4+nc, 33600), boxes random cxcywh on a 1280 canvas,
     ~15 % of the anchors confident (several thousand candidates per image after conf_thres 0.25, >= 300 kept)."""
@@ -378,6 +427,7 @@ def main():
         try:
             extra["preset_l_640_bf16_16img"] = measure_preset("l", 16, args.res, nc, dev, steps=20, warmup=5)
             extra["nms_config5_fp16_8img"] = measure_nms(dev)
+            extra["preset_l_fsdp2_bf16_16img"] = measure_fsdp2("l", 16, args.res, nc, dev, steps=10, warmup=3)
         except Exception as e:                     # never lose the headline line to an extra
             extra["error"] = repr(e)
 

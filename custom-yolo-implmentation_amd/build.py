@@ -21,6 +21,16 @@ BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-un
 NO_CONTRACT = {"loss.hip", "decode_nms.hip", "image_prep.hip"}   # + the uint8-level arithmetic of the input pipeline
 
 
+def abi_hash(header):
+    """63-bit hash of the header's prototypes: compiled into the library (yolo_abi_hash) and checked by the loader, so a
+    stale .so next to a newer header is an error at load time instead of shifted arguments at call time."""
+    import hashlib
+    import re
+    protos = re.findall(r"^(?:int|long|size_t)\s+yolo_\w+\s*\([^)]*\)\s*;", open(header).read(), re.M)
+    text = "\n".join(p for p in protos if "yolo_abi_hash" not in p)
+    return int.from_bytes(hashlib.sha1(text.encode()).digest()[:8], "little") >> 1
+
+
 def newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -35,6 +45,8 @@ def build(force=False, verbose=True):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest([src] + hdrs):
             flags = BASE + (["-ffp-contract=off"] if s in NO_CONTRACT else [])
+            if s == "abi.hip":
+                flags = flags + [f"-DYOLO_ABI_HASH={abi_hash(hdrs[-1])}L"]
             jobs.append((s, [HIPCC] + flags + ["-c", src, "-o", obj]))
 
     def run(job):

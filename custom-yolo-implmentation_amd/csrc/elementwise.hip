@@ -406,10 +406,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 }
 
 // acc[8][2][C] -> mean, invstd, scale, shift (+ running statistics): one thread per channel, 16 loads
-__global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, int C, PIn gamma,
-                                  PIn beta, PIo rmean, PIo rvar,
+__global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, int C, const void* __restrict__ gamma_,
+                                  const void* __restrict__ beta_, void* __restrict__ rmean_, void* __restrict__ rvar_,
                                   float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
-                                  float* __restrict__ scale, float* __restrict__ shift) {
+                                  float* __restrict__ scale, float* __restrict__ shift, int pdt, int bdt) {
+    const PIn gamma{gamma_, pdt}; const PIn beta{beta_, pdt}; const PIo rmean{rmean_, bdt}, rvar{rvar_, bdt};
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
@@ -437,10 +438,11 @@ __global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, in
 // k_bn_finalize_acc.
 template <typename T, int V, int ACT>
 __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ y, int ldy, const float* __restrict__ acc, float count,
-                        PIn gamma, PIn beta, PIo rmean,
-                        PIo rvar, float momentum, float eps, float* __restrict__ mean_out,
+                        const void* __restrict__ gamma_, const void* __restrict__ beta_, void* __restrict__ rmean_,
+                        void* __restrict__ rvar_, float momentum, float eps, float* __restrict__ mean_out,
                         float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
-                        const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C, int act, int tpr) {
+                        const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C, int act, int tpr, int pdt, int bdt) {
+    const PIn gamma{gamma_, pdt}; const PIn beta{beta_, pdt}; const PIo rmean{rmean_, bdt}, rvar{rvar_, bdt};
     extern __shared__ float cf[];                            // [2][cw]: scale, shift of this workgroup's channels
     const int cv = C / V;
     const int rpb = TPB / tpr;
@@ -516,10 +518,11 @@ template <typename T, int V, int ACT>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __restrict__ y, int ldy,
                               const float* __restrict__ scale, const float* __restrict__ shift,
-                              PIn gamma, const float* __restrict__ mean,
+                              const void* __restrict__ gamma_, const float* __restrict__ mean,
                               const float* __restrict__ invstd, const float* __restrict__ acc, float count,
-                              PIo dgamma, PIo dbeta, T* __restrict__ dy, int lddy,
-                              long npix, int C, int act, int tpr) {
+                              void* __restrict__ dgamma_, void* __restrict__ dbeta_, T* __restrict__ dy, int lddy,
+                              long npix, int C, int act, int tpr, int pdt) {
+    const PIn gamma{gamma_, pdt}; const PIo dgamma{dgamma_, pdt}, dbeta{dbeta_, pdt};
     extern __shared__ float cf[];                            // [5][cw]: scale, shift, A, B, D
     const int cv = C / V;
     const int rpb = TPB / tpr;
@@ -538,7 +541,7 @@ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __re
             v2 = (float)k0;
             v3 = (float)(-k0 * c2 * is);
             v4 = (float)(-k0 * c1 + k0 * c2 * mu * is);
-            if (blockIdx.x == 0) { dbeta[c] = (float)s; dgamma.ld(c) = (float)q; }
+            if (blockIdx.x == 0) { dbeta.st(c, (float)s); dgamma.st(c, (float)q); }
         }
         cf[t] = v0; cf[cw + t] = v1; cf[2 * cw + t] = v2; cf[3 * cw + t] = v3; cf[4 * cw + t] = v4;
     }
@@ -601,10 +604,11 @@ __device__ __forceinline__ int fin_reduce(const float* __restrict__ partial, int
 // finalize for training-mode BN: batch mean / biased var -> invstd, scale, shift; running stats
 // updated with momentum and the unbiased variance (torch.nn.BatchNorm2d semantics).
 __global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, float count, int C,
-                              PIn gamma, PIn beta,
-                              PIo rmean, PIo rvar, float momentum, float eps,
+                              const void* __restrict__ gamma_, const void* __restrict__ beta_,
+                              void* __restrict__ rmean_, void* __restrict__ rvar_, float momentum, float eps,
                               float* __restrict__ mean, float* __restrict__ invstd,
-                              float* __restrict__ scale, float* __restrict__ shift) {
+                              float* __restrict__ scale, float* __restrict__ shift, int pdt, int bdt) {
+    const PIn gamma{gamma_, pdt}; const PIn beta{beta_, pdt}; const PIo rmean{rmean_, bdt}, rvar{rvar_, bdt};
     double s, q;
     const int c = fin_reduce(partial, nblk, C, s, q);
     if (c < 0) return;
@@ -624,9 +628,10 @@ __global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, float
     }
 }
 
-__global__ void k_bn_eval_coeffs(PIn gamma, PIn beta,
-                                 PIn rmean, PIn rvar, float eps,
-                                 int C, float* __restrict__ scale, float* __restrict__ shift) {
+__global__ void k_bn_eval_coeffs(const void* __restrict__ gamma_, const void* __restrict__ beta_,
+                                 const void* __restrict__ rmean_, const void* __restrict__ rvar_, float eps,
+                                 int C, float* __restrict__ scale, float* __restrict__ shift, int pdt, int bdt) {
+    const PIn gamma{gamma_, pdt}; const PIn beta{beta_, pdt}; const PIn rmean{rmean_, bdt}, rvar{rvar_, bdt};
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float g = gamma.ld(c) / sqrtf(rvar.ld(c) + eps);
@@ -636,14 +641,15 @@ __global__ void k_bn_eval_coeffs(PIn gamma, PIn beta,
 
 // backward finalize: dgamma = sum dz*yhat, dbeta = sum dz, coef = [gamma*invstd, dbeta/m, dgamma/m]
 __global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, float count, int C,
-                                  PIn gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                  PIo dgamma, PIo dbeta, float* __restrict__ coef) {
+                                  const void* __restrict__ gamma_, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  void* __restrict__ dgamma_, void* __restrict__ dbeta_, float* __restrict__ coef, int pdt) {
+    const PIn gamma{gamma_, pdt}; const PIo dgamma{dgamma_, pdt}, dbeta{dbeta_, pdt};
     double s, q;
     const int c = fin_reduce(partial, nblk, C, s, q);
     if (c < 0) return;
     q = (double)invstd[c] * (q - (double)mean[c] * s);      // partial rows hold sum(dz*y): -> sum(dz*yhat)
-    dbeta[c] = (float)s;
-    dgamma.ld(c) = (float)q;
+    dbeta.st(c, (float)s);
+    dgamma.st(c, (float)q);
     // dy = k0*(dz - c1 - yhat*c2), yhat = (y-mean)*invstd  ==  A*dz + B*y + D  (three constants per channel)
     const double k0 = (double)gamma.ld(c) * invstd[c], c1 = s / count, c2 = q / count;
     coef[c] = (float)k0;
@@ -1134,16 +1140,15 @@ int yolo_bn_finalize(const float* partial, int nblk, long count, int C, const vo
                      float* invstd, float* scale, float* shift, int pdtype, int bdtype, hipStream_t st) {
     if (!pdt_ok(pdtype) || !pdt_ok(bdtype)) return YOLO_ERR_DTYPE;
     hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk, (float)count, C,
-                       PIn{gamma, pdtype}, PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps,
-                       mean, invstd, scale, shift);
+                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, pdtype, bdtype);
     return YOLO_LAUNCH_CHECK();
 }
 
 int yolo_bn_eval_coeffs(const void* gamma, const void* beta, const void* running_mean, const void* running_var,
                         float eps, int C, float* scale, float* shift, int pdtype, int bdtype, hipStream_t st) {
     if (!pdt_ok(pdtype) || !pdt_ok(bdtype)) return YOLO_ERR_DTYPE;
-    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ceil_div(C, 128)), dim3(128), 0, st, PIn{gamma, pdtype}, PIn{beta, pdtype},
-                       PIn{running_mean, bdtype}, PIn{running_var, bdtype}, eps, C, scale, shift);
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ceil_div(C, 128)), dim3(128), 0, st, gamma, beta, running_mean, running_var, eps, C,
+                       scale, shift, pdtype, bdtype);
     return YOLO_LAUNCH_CHECK();
 }
 
@@ -1175,7 +1180,7 @@ int yolo_bn_bwd_finalize(const float* partial, int nblk, long count, int C, cons
                          const float* invstd, void* dgamma, void* dbeta, float* coef, int pdtype, hipStream_t st) {
     if (!pdt_ok(pdtype)) return YOLO_ERR_DTYPE;
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_PARTS), 0, st, partial, nblk,
-                       (float)count, C, PIn{gamma, pdtype}, mean, invstd, PIo{dgamma, pdtype}, PIo{dbeta, pdtype}, coef);
+                       (float)count, C, gamma, mean, invstd, dgamma, dbeta, coef, pdtype);
     return YOLO_LAUNCH_CHECK();
 }
 
@@ -1226,8 +1231,8 @@ int yolo_bn_finalize_acc(const float* acc, long count, int C, const void* gamma,
                          void* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                          float* shift, int pdtype, int bdtype, hipStream_t st) {
     if (!pdt_ok(pdtype) || !pdt_ok(bdtype)) return YOLO_ERR_DTYPE;
-    hipLaunchKernelGGL(k_bn_finalize_acc, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, (float)count, C, PIn{gamma, pdtype},
-                       PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps, mean, invstd, scale, shift);
+    hipLaunchKernelGGL(k_bn_finalize_acc, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, (float)count, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, pdtype, bdtype);
     return YOLO_LAUNCH_CHECK();
 }
 
@@ -1242,12 +1247,12 @@ int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, 
             const RsPlan pl = rs_plan(npix, C / V);
             if (act)
                 hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 1>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
-                               (const T*)y, ldy, acc, (float)count, PIn{gamma, pdtype}, PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps,
-                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr);
+                               (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr, pdtype, bdtype);
             else
                 hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 0>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
-                               (const T*)y, ldy, acc, (float)count, PIn{gamma, pdtype}, PIn{beta, pdtype}, PIo{running_mean, bdtype}, PIo{running_var, bdtype}, momentum, eps,
-                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr);
+                               (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr, pdtype, bdtype);
         });
     });
     return YOLO_LAUNCH_CHECK();
@@ -1270,12 +1275,12 @@ int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ld
             const RsPlan pl = rs_plan(npix, C / V);
             if (act)
                 hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 1>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
-                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, PIn{gamma, pdtype}, mean, invstd, acc, (float)count,
-                               PIo{dgamma, pdtype}, PIo{dbeta, pdtype}, (T*)dy, lddy, npix, C, act, pl.tpr);
+                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
+                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr, pdtype);
             else
                 hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 0>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
-                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, PIn{gamma, pdtype}, mean, invstd, acc, (float)count,
-                               PIo{dgamma, pdtype}, PIo{dbeta, pdtype}, (T*)dy, lddy, npix, C, act, pl.tpr);
+                               (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
+                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr, pdtype);
         });
     });
     return YOLO_LAUNCH_CHECK();

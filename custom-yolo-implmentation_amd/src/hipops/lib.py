@@ -29,7 +29,7 @@ def parse_header(path=None):
     protos = {}
     for ret, name, args in _PROTO.findall(open(path).read()):
         types, names = [], []
-        for a in [s.strip() for s in args.split(",") if s.strip()]:
+        for a in [s.strip() for s in args.split(",") if s.strip() and s.strip() != "void"]:
             toks = a.replace("*", " * ").split()
             names.append(toks[-1])
             types.append(ctypes.c_void_p if "*" in toks else _CT[[t for t in toks[:-1] if t != "const"][0]])
@@ -53,8 +53,21 @@ def load():
     for name, (ret, types, _) in _protos.items():
         fn = getattr(lib, name)        # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = ret, types
+    want = _header_hash()
+    if lib.yolo_abi_hash() != want:
+        raise RuntimeError(f"libyolo_hip.so was built against another include/yolo_hip.h (ABI hash {lib.yolo_abi_hash()} != "
+                           f"{want}): rebuild it with `python custom-yolo-implmentation_amd/build.py` and check that the build succeeds")
     _lib = lib
     return lib
+
+
+def _header_hash():
+    """Same hash as build.py's abi_hash()."""
+    import hashlib
+    path = next(p for p in HEADER_PATHS if os.path.exists(p))
+    protos = re.findall(r"^(?:int|long|size_t)\s+yolo_\w+\s*\([^)]*\)\s*;", open(path).read(), re.M)
+    text = "\n".join(p for p in protos if "yolo_abi_hash" not in p)
+    return int.from_bytes(hashlib.sha1(text.encode()).digest()[:8], "little") >> 1
 
 
 def status(rc, name):

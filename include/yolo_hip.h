@@ -44,6 +44,9 @@ typedef struct ihipStream_t* hipStream_t;
 #define YOLO_ACT_IDENTITY 0
 #define YOLO_ACT_SILU 1
 
+/* hash of this header's prototypes at build time; the loader refuses a library built against another header */
+long yolo_abi_hash(void);
+
 /* ---- layout / copies (replace .view/.transpose/torch.cat/.chunk copies: head.py:87,119, model_blocks.py:92,123-125,156,249-252, neck.py:41-44) */
 int yolo_memset0(void* p, size_t bytes, hipStream_t st);
 int yolo_ncm_to_nhwc(const void* src, int src_dtype, long sn, long sc, long off, void* dst, int dst_dtype, int ld, int N, int C, int HW, hipStream_t st);
