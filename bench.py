@@ -185,11 +185,21 @@ def measure_fsdp2(preset, batch, res, nc, dev, steps, warmup, precision="bfloat1
     from src.model.model_builder import Model
     from src.training.utils_train import get_optimizer, prepare_fsdp2_model
     own = not dist.is_initialized()
-    if own:
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    # RCCL prints its version banner to STDOUT when the communicator comes up; bench.py's stdout carries exactly one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if own:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     try:
         torch.manual_seed(0)
         model = Model(**PRESETS[preset], num_classes=nc)

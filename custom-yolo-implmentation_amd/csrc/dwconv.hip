@@ -26,9 +26,11 @@ template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4& v, floa
 template <> __device__ __forceinline__ void unpack8<f16_t>(const u32x4& v, float (&o)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const h16x2 h = __builtin_bit_cast(h16x2, v[i]);
-        o[2 * i] = (float)h.x;
-        o[2 * i + 1] = (float)h.y;
+        // (a bit_cast of the vector ELEMENT to a half2 was miscompiled for i >= 1: channels 2..7 of every packet came out
+        // wrong in fp16 while bf16 was exact -- found by the FSDP2 fp16 parity test, tests/test_gpu_kernels.py::test_depthwise)
+        const unsigned int u = v[i];
+        o[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+        o[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
     }
 }
 

@@ -64,7 +64,7 @@ def check(got, want, dtype, what, scale=None, mult=1.0):
 
 
 # ------------------------------------------------------------------------------------------ layout / copies
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shapes", [[(9, 7), (5, 4), (3, 2)], [(16, 12), (8, 8), (2, 4)], [(80, 80), (40, 40), (20, 20)]])
 def test_head_group_equals_per_branch_pack_and_unpack(dtype, shapes):
     """all six branch tensors <-> (N, no, M) in one launch == one transposing launch per branch; odd maps (2-byte form),
@@ -90,7 +90,7 @@ def test_head_group_equals_per_branch_pack_and_unpack(dtype, shapes):
 
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_to_nhwc_and_head_pack_roundtrip(dtype):
     o = ops()
     x = rnd(2, 37, 9, 11, seed=1)
@@ -166,7 +166,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, algo, monkeypatch):
     check(dw, dw_ref, torch.float32, "conv_wgrad", mult=4.0)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("h,w", [(32, 32), (17, 23)])
 def test_stem_unfold_path(dtype, h, w):
     o = ops()
@@ -246,7 +246,7 @@ def test_stem_fused_wgrad(dtype, cout, h, w, pad):
     assert dwb.dtype == torch.bfloat16 and torch.equal(dwb.float().cpu(), dw.cpu().to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("c,h,w", [(16, 12, 12), (24, 7, 9), (128, 10, 10), (80, 13, 21), (512, 20, 20), (12, 5, 6), (2056, 3, 5)])
 def test_depthwise(dtype, c, h, w):
     """odd maps (partial row strips and column blocks), channel groups that do not divide a workgroup (24, 80), more
@@ -269,7 +269,7 @@ def test_depthwise(dtype, c, h, w):
 
 
 # ------------------------------------------------------------------------------------------ BN + act
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("c,act,pad", [(16, 1, 0), (24, 0, 8), (96, 1, 0), (6, 1, 0)])
 def test_bn_act_train_fwd_bwd(dtype, c, act, pad):
     o = ops()
@@ -300,7 +300,7 @@ def test_bn_act_train_fwd_bwd(dtype, c, act, pad):
     check(sc, sc_r, torch.float32, "eval scale"), check(sh, sh_r, torch.float32, "eval shift")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,h,w,k,s,act", [(16, 32, 20, 20, 3, 1, 1), (32, 128, 17, 13, 1, 1, 0), (64, 24, 16, 16, 3, 2, 1)])
 def test_bn_accumulator_path_with_conv_epilogue_stats(dtype, cin, cout, h, w, k, s, act):
     """conv writes y AND its channel sums; act kernel derives mean/invstd; backward reduce + apply from acc."""
@@ -342,7 +342,7 @@ def test_bn_accumulator_path_with_conv_epilogue_stats(dtype, cin, cout, h, w, k,
 
 
 # ------------------------------------------------------------------------------------------ pool / upsample
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_maxpool5_and_upsample(dtype):
     o = ops()
     x = nhwc((rnd(2, 24, 9, 10, seed=40) * 2).round().div(2).to(dtype))        # many exact ties
@@ -420,7 +420,7 @@ def test_loss_golden_n320_fp32():
     assert abs(float(dp.double().abs().sum()) - float(gd["dpreds_abs"])) <= 1e-5 * float(gd["dpreds_abs"])
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_loss_random_s640_shape(dtype):
     """N=4, A=8400, nc=80, 1..20 GTs per image (COCO-shaped synthetic targets)."""
     from oracle.blocks import make_anchors
