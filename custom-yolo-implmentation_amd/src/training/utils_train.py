@@ -135,23 +135,46 @@ def prepare_ddp_model(model: nn.Module, device_id: int, config: Dict[str, Union[
     return ddp
 
 
+def _fsdp1_wrap_policy(min_num_params: int):
+    """size_based_auto_wrap_policy(min_num_params) restricted to modules whose `forward` this package really calls (the
+    block classes of src.model: Conv, Residual, C3K, C3K2, SPPF, Attention, PSABlock, PSA, Backbone, Neck, Head).  A bare
+    nn.Conv2d / nn.BatchNorm2d is a parameter container here (the enclosing block reads its parameters inside ITS forward)
+    and nn.Sequential / nn.ModuleList members are iterated by the blocks (each producer writes into its slice of the
+    consumer's concat buffer), so their own `forward` never runs: as FSDP units they would never be unsharded."""
+    size_policy = functools.partial(size_based_auto_wrap_policy, min_num_params=int(min_num_params))
+
+    def policy(module, recurse, nonwrapped_numel):
+        if recurse:
+            return True
+        if not type(module).__module__.startswith("src.model."):
+            return False
+        return size_policy(module=module, recurse=False, nonwrapped_numel=nonwrapped_numel)
+    return policy
+
+
 def prepare_fsdp_model(model: nn.Module, device_id: int, config: Dict[str, Union[str, int]], world_size: int,
                        device: str) -> nn.Module:
-    """FSDP1 (reference :58-114).  Deviation, on purpose: the reference compares the configured strategy with
-    "FULLY_SHARD" (not a ShardingStrategy name), so config.yaml's "FULL_SHARD" silently ran NO_SHARD; here any
-    valid ShardingStrategy name is honoured."""
+    """FSDP1 (reference :58-114).  Two deviations, on purpose:
+    * the reference compares the configured strategy with "FULLY_SHARD" (not a ShardingStrategy name), so config.yaml's
+      "FULL_SHARD" silently ran NO_SHARD; here any valid ShardingStrategy name is honoured;
+    * under mixed precision torch wraps every BatchNorm2d as a separate fp32 FSDP unit by default
+      (`MixedPrecision._module_classes_to_ignore`).  Such a unit is unsharded only around the BatchNorm module's own
+      forward, which the fused Conv block never calls; the BatchNorm parameters therefore stay in the enclosing unit and
+      follow `param_dtype` / `buffer_dtype` like every other parameter -- the contract of the reference's FSDP2 path
+      (:146-153); the kernels take them in that dtype and compute the normalisation in fp32 either way."""
     _pin_device(device, device_id, world_size)
     mp = None
     if config["precision"] in _LOWP:
         print("[INFO] Setting up precision - {}".format(config["precision"]))
         dt = getattr(torch, config["precision"])
-        mp = MixedPrecision(param_dtype=dt, reduce_dtype=dt, buffer_dtype=dt, cast_forward_inputs=True)
+        mp = MixedPrecision(param_dtype=dt, reduce_dtype=dt, buffer_dtype=dt, cast_forward_inputs=True,
+                            _module_classes_to_ignore=())
     strategy = ShardingStrategy.NO_SHARD
     name = str(config.get("sharding_strategy", "NO_SHARD"))
     if world_size != 1 and name in ShardingStrategy.__members__:
         strategy = ShardingStrategy[name]
     mesh = init_device_mesh("cuda" if device == "cuda" else "cpu", (world_size,))
-    policy = functools.partial(size_based_auto_wrap_policy, min_num_params=int(config["auto_wrap_policy_min_params"]))
+    policy = _fsdp1_wrap_policy(config["auto_wrap_policy_min_params"])
     return FSDP(model, auto_wrap_policy=policy, sharding_strategy=strategy, mixed_precision=mp, use_orig_params=True,
                 device_id=device_id if device == "cuda" else torch.device("cpu"), device_mesh=mesh).to(device)
 

@@ -74,7 +74,12 @@ def test_sharded_wrappers_predictions_and_all_gradients(pg, wrapper, preset, pre
     assert preds.dtype == (lowp or torch.float32) and a.dtype == preds.dtype
     ct = _cotangent(tuple(preds.shape), 4)
     preds.backward(ct.to(preds.dtype).cuda())
-    grads = {_canon(k): _full(p.grad) for k, p in model.named_parameters() if p.grad is not None}
+    if wrapper == "fsdp":          # FSDP1 keeps the gradients on its flat parameters: views per original parameter on request
+        from torch.distributed.fsdp import FullyShardedDataParallel as FSDP
+        with FSDP.summon_full_params(model, with_grads=True):
+            grads = {_canon(k): p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    else:
+        grads = {_canon(k): _full(p.grad) for k, p in model.named_parameters() if p.grad is not None}
     assert all(g.dtype == torch.float32 for g in grads.values())          # the sharded masters and their gradients stay fp32
     bufs = {_canon(k): b for k, b in model.named_buffers()}
 

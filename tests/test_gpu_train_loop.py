@@ -408,7 +408,7 @@ def test_eval_after_captured_steps_uses_the_updated_weights():
 
 
 def _ddp_rank(rank, world, port, out):
-    """One of two ranks sharing the GPU over gloo: train() on a DDP-wrapped model through the captured default path, rank 1
+    """One of two ranks sharing the GPU over gloo: train(captured_step=True) on a DDP-wrapped model through the captured path, rank 1
     gets one batch with more boxes than the captured capacity (-> every rank must step that batch eagerly)."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -453,7 +453,7 @@ def _ddp_rank(rank, world, port, out):
     with tempfile.TemporaryDirectory() as d:
         tm.train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched, criterion=YoloDFLQFLoss(num_classes=80),
                  initial_epoch=0, num_epochs=1, device=0, num_classes=80, rank=rank, checkpoint_dir=d, distributed_mode="ddp",
-                 precision="bfloat16", conf_threshold=0.01)
+                 precision="bfloat16", conf_threshold=0.01, captured_step=True)      # opt-in with more than one rank
     flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()]).cpu()
     bufs = torch.cat([b.detach().float().reshape(-1) for b in model.buffers()]).cpu()
     both_w = [torch.zeros_like(flat) for _ in range(world)]
