@@ -149,8 +149,10 @@ class KernelTimer:
         return groups
 
 
-def measure_preset(preset, batch, res, nc, dev, steps, warmup):
-    """The same captured training step on another preset (extra data point, not the metric)."""
+def measure_preset(preset, batch, res, nc, dev, steps, warmup, deterministic=False):
+    """The same captured training step on another preset (extra data point, not the metric).  `deterministic`: the
+    package's deterministic mode (fixed-order BatchNorm statistics instead of float atomics): the price of bit-reproducibility."""
+    from src.hipops import functions as F_
     from src.model.losses import PackedTargets, YoloDFLQFLoss
     from src.model.model_builder import Model
     from src.training.fused_adamw import HipAdamW
@@ -159,8 +161,12 @@ def measure_preset(preset, batch, res, nc, dev, steps, warmup):
     model = Model(**PRESETS[preset], num_classes=nc).to(dev).train()
     opt = HipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
     img, gts = synthetic_batch(batch, res, nc, 4321, dev)
-    runner = TrainStepRunner(model, YoloDFLQFLoss(num_classes=nc), opt, "bfloat16", use_graph=True)
-    runner.capture(img, PackedTargets(gts, dev))
+    was, F_.DETERMINISTIC = F_.DETERMINISTIC, deterministic
+    try:
+        runner = TrainStepRunner(model, YoloDFLQFLoss(num_classes=nc), opt, "bfloat16", use_graph=True)
+        runner.capture(img, PackedTargets(gts, dev))
+    finally:
+        F_.DETERMINISTIC = was
     for _ in range(warmup):
         runner.step()
     torch.cuda.synchronize()
@@ -437,6 +443,7 @@ def main():
         try:
             extra["preset_l_640_bf16_16img"] = measure_preset("l", 16, args.res, nc, dev, steps=20, warmup=5)
             extra["nms_config5_fp16_8img"] = measure_nms(dev)
+            extra["preset_s_640_bf16_32img_deterministic_mode"] = measure_preset("s", args.batch, args.res, nc, dev, steps=10, warmup=3, deterministic=True)
             extra["preset_l_fsdp2_bf16_16img"] = measure_fsdp2("l", 16, args.res, nc, dev, steps=10, warmup=3)
         except Exception as e:                     # never lose the headline line to an extra
             extra["error"] = repr(e)

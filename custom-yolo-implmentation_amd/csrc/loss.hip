@@ -136,8 +136,9 @@ __device__ __forceinline__ void qfl_elem0(float x, float& val, float& dx) {
 // the box region only gets its zero gradient written.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_dense(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds, float coef,
-                                               double* __restrict__ partial) {
+                                               double* __restrict__ partial, const float* __restrict__ grad_scale) {
     __shared__ float red[4];
+    if (grad_scale) coef *= *grad_scale;                     // fp16 loss scaling: applied in fp32, before the one rounding
     const int Cp = 4 * REG + d.nc;
     const int P = d.nc * (d.A / V), Z = 4 * REG * (d.A / V);  // packets per image: class region, box region (host: A % V == 0)
     const int nthr = gridDim.x * 256, gtid = blockIdx.x * 256 + threadIdx.x;
@@ -191,8 +192,10 @@ __global__ __launch_bounds__(256) void k_matched(LossDims d, const T* __restrict
                                                  const T* __restrict__ anchors, const T* __restrict__ strides,
                                                  const float4* __restrict__ pbox, const float* __restrict__ gt,
                                                  const int* __restrict__ gt_off, const int* __restrict__ idx,
-                                                 double* __restrict__ img_dfl, double* __restrict__ img_cls_fix) {
+                                                 double* __restrict__ img_dfl, double* __restrict__ img_cls_fix,
+                                                 const float* __restrict__ grad_scale) {
     __shared__ double w_dfl[4], w_cls[4];
+    const float gsc = grad_scale ? *grad_scale : 1.f;
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g0 = gt_off[n], M = gt_off[n + 1] - g0;
     const int Cp = 4 * REG + d.nc;
@@ -279,10 +282,10 @@ __global__ __launch_bounds__(256) void k_matched(LossDims d, const T* __restrict
                 qfl_elem(xc, 0.f, v0, g0_);
                 qfl_elem(xc, iou, v1, g1_);
                 acc_cls += (double)v1 - (double)v0;
-                if (dn) dn[(long)(4 * REG + cls) * d.A + a] = from_f<T>(g1_ * ccls);
+                if (dn) dn[(long)(4 * REG + cls) * d.A + a] = from_f<T>(g1_ * ccls * gsc);
             }
         }
-        if (dn) dn[(long)lane * d.A + a] = from_f<T>(gacc);
+        if (dn) dn[(long)lane * d.A + a] = from_f<T>(gacc * gsc);
     }
     if (lane == 0) { w_dfl[wave] = acc_dfl; w_cls[wave] = acc_cls; }
     __syncthreads();
@@ -345,10 +348,13 @@ size_t yolo_loss_workspace_bytes(int N, int A, int G) {
 
 // gt: fp32 [G][5] (cx,cy,w,h,cls, pixels) grouped by image; gt_off: int32 [N+1]; gt_img: int32 [G].  G is the number of
 // ROWS of gt / gt_img; the live count is gt_off[N] <= G, read on the device (a captured step refills the buffers).
-// dpreds may be null (validation).  out: fp32[3] = {total, mean_dfl ("box_loss"), mean_cls}.
+// dpreds may be null (validation).  out: fp32[3] = {total, mean_dfl ("box_loss"), mean_cls} (never scaled).
+// grad_scale: optional DEVICE scalar (fp16 loss scaling, train_model.py:247-253): dpreds = scale * d total / d preds, the
+// factor applied in fp32 before the gradient is rounded to T -- what `scaler.scale(loss).backward()` computes in the
+// reference, where the scaled loss gradient is formed in fp32 and cast at the `.float()` boundary (losses.py:142).
 int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A,
                       const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl,
-                      float lambda_cls, void* dpreds, float* out, void* workspace, hipStream_t st) {
+                      float lambda_cls, void* dpreds, float* out, void* workspace, const float* grad_scale, hipStream_t st) {
     LossDims d{N, A, nc, lambda_dfl, lambda_cls};
     char* ws = (char*)workspace;
     float4* pbox = (float4*)ws;
@@ -372,10 +378,10 @@ int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* stride
         if (nblk < 1) nblk = 1;
         int rc = yolo_zero_async(partial, DENSE_BLOCKS * sizeof(double), st);
         if (rc) return rc;
-        if (vec) hipLaunchKernelGGL((k_dense<T, VV>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial);
-        else hipLaunchKernelGGL((k_dense<T, 1>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial);
+        if (vec) hipLaunchKernelGGL((k_dense<T, VV>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial, grad_scale);
+        else hipLaunchKernelGGL((k_dense<T, 1>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial, grad_scale);
         hipLaunchKernelGGL((k_matched<T>), dim3(N), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, (const T*)anchors,
-                           (const T*)strides, pbox, gt, gt_off, idx, img_dfl, img_fix);
+                           (const T*)strides, pbox, gt, gt_off, idx, img_dfl, img_fix, grad_scale);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, d, partial, DENSE_BLOCKS, img_dfl, img_fix, out);
     });
     return YOLO_LAUNCH_CHECK();

@@ -94,6 +94,52 @@ __global__ __launch_bounds__(256) void k_adamw(const AdamJob* __restrict__ jobs,
     }
 }
 
+// ---- fp16 loss scaling on the device (torch.amp.GradScaler's protocol, reference src/training/train_model.py:195-208,
+// 247-253, without its host round trips): found_inf over every gradient of the job table, then the optimizer kernel above
+// (which skips on found_inf and unscales in flight), then the scale update -- all launches of a captured step.
+__global__ __launch_bounds__(256) void k_found_inf(const AdamJob* __restrict__ jobs, int njobs, float* __restrict__ found_inf) {
+    __shared__ int sj;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].cstart <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        sj = lo;
+    }
+    __syncthreads();
+    const AdamJob j = jobs[sj];
+    const long base = ((long)blockIdx.x - j.cstart) * CHUNK;
+    bool bad = false;
+    for (long i = base + threadIdx.x; i < base + CHUNK && i < j.n; i += 256) {
+        const float g = ld_any(j.g, j.g_dtype, i);
+        bad |= !(fabsf(g) <= 3.4028234664e38f);             // inf or nan
+    }
+    if (bad) *found_inf = 1.f;                                // every writer stores the same value
+}
+
+// state = [scale, found_inf, last_found_inf] (fp32), tracker = successful steps since the last change.
+// torch's _amp_update_scale_: overflow -> scale *= backoff, tracker = 0; else tracker + 1 == interval -> scale *= growth
+// (if still finite), tracker = 0; else tracker += 1.  found_inf is handed on as last_found_inf and cleared for the next step.
+__global__ void k_amp_update(float* __restrict__ state, int* __restrict__ tracker, float growth, float backoff, int interval) {
+    const float found = state[1];
+    if (found != 0.f) {
+        state[0] *= backoff;
+        *tracker = 0;
+    } else {
+        const int ok = *tracker + 1;
+        if (ok == interval) {
+            const float ns = state[0] * growth;
+            if (fabsf(ns) <= 3.4028234664e38f) state[0] = ns;
+            *tracker = 0;
+        } else {
+            *tracker = ok;
+        }
+    }
+    state[2] = found;
+    state[1] = 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -135,6 +181,20 @@ int yolo_adamw_step(const void* jobs_dev, int njobs, long nchunks, const double*
     hipLaunchKernelGGL(k_adamw_tick, dim3(1), dim3(1), 0, st, step, found_inf);
     hipLaunchKernelGGL(k_adamw, dim3((unsigned)nchunks), dim3(256), 0, st, (const AdamJob*)jobs_dev, njobs, hyper, step,
                        grad_scale, found_inf);
+    return YOLO_LAUNCH_CHECK();
+}
+
+// One optimizer step under dynamic loss scaling, all on the device: amp_state = [scale, found_inf (0 on entry), last_found_inf].
+// The gradients of the job table carry the factor `scale` (the loss kernel multiplied its gradient by it in fp32).
+int yolo_adamw_amp_step(const void* jobs_dev, int njobs, long nchunks, const double* hyper, float* step, float* amp_state,
+                        int* growth_tracker, float growth_factor, float backoff_factor, int growth_interval, hipStream_t st) {
+    if (njobs <= 0 || nchunks <= 0) return YOLO_OK;
+    if (!(growth_factor >= 1.f) || !(backoff_factor > 0.f && backoff_factor <= 1.f) || growth_interval < 1) return YOLO_ERR_ARG;
+    hipLaunchKernelGGL(k_found_inf, dim3((unsigned)nchunks), dim3(256), 0, st, (const AdamJob*)jobs_dev, njobs, amp_state + 1);
+    hipLaunchKernelGGL(k_adamw_tick, dim3(1), dim3(1), 0, st, step, amp_state + 1);
+    hipLaunchKernelGGL(k_adamw, dim3((unsigned)nchunks), dim3(256), 0, st, (const AdamJob*)jobs_dev, njobs, hyper, step,
+                       amp_state, amp_state + 1);
+    hipLaunchKernelGGL(k_amp_update, dim3(1), dim3(1), 0, st, amp_state, growth_tracker, growth_factor, backoff_factor, growth_interval);
     return YOLO_LAUNCH_CHECK();
 }
 

@@ -781,6 +781,11 @@ class HeadPack(torch.autograd.Function):
 # incoming gradient is exactly 1.0 and the in-place scale of dpreds (77 MB read + written, 30 us at the head of the backward
 # chain) is the identity.  Everywhere else the gradient is applied as it comes (GradScaler, weighted sums of losses).
 UNIT_LOSS_SEED = False
+# fp16 loss scaling on the device (TrainStepRunner with precision float16): an fp32 device scalar the loss kernel multiplies
+# its gradient by IN FP32, before the one rounding to fp16 -- `scaler.scale(loss).backward()` of the reference
+# (src/training/train_model.py:247-253), where the scaled gradient is formed in fp32 and cast at `preds.float()`.  The
+# loss VALUE stays unscaled.  None everywhere else (a torch GradScaler's factor then arrives as the incoming gradient).
+LOSS_SCALE = None
 
 
 class DflQflLoss(torch.autograd.Function):
@@ -792,7 +797,7 @@ class DflQflLoss(torch.autograd.Function):
         gt, gt_off, gt_img, n_gt = packed
         want = ctx.needs_input_grad[0]
         out, dpreds, _ = ops.loss_fwd_bwd(preds.contiguous(), anchors, strides, gt, gt_off, gt_img, n_gt, nc,
-                                          lambda_dfl, lambda_cls, want)
+                                          lambda_dfl, lambda_cls, want, LOSS_SCALE if want else None)
         ctx.dpreds = dpreds
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out

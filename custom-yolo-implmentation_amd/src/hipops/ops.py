@@ -575,8 +575,10 @@ def attn_bwd(qkv, o, d_o, d_vp, stash, heads, dk, dh, scale):
 
 
 # ------------------------------------------------------------------------------------------------ loss / post
-def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_dfl, lambda_cls, want_grad):
-    """-> (out[3] fp32 = total, mean_dfl, mean_cls ; dpreds or None)."""
+def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_dfl, lambda_cls, want_grad, grad_scale=None):
+    """-> (out[3] fp32 = total, mean_dfl, mean_cls ; dpreds or None).  `grad_scale`: optional fp32 device scalar the
+    gradient is multiplied by in fp32 before it is rounded to the prediction dtype (fp16 loss scaling)."""
+    assert grad_scale is None or (grad_scale.dtype == torch.float32 and grad_scale.is_cuda)
     n, cp, a = preds.shape
     assert preds.is_contiguous() and cp == 64 + nc
     anchors = anchors.to(preds.dtype).contiguous()
@@ -585,7 +587,7 @@ def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_d
     out = _f32(3, preds.device)
     dpreds = torch.empty_like(preds) if want_grad else None
     lib.call("yolo_loss_dfl_qfl", _p(preds), _p(anchors), _p(strides), dt(preds), n, nc, a, _p(gt), _p(gt_off),
-             _p(gt_img), n_gt, float(lambda_dfl), float(lambda_cls), _p(dpreds), _p(out), _p(ws), _stream(preds))
+             _p(gt_img), n_gt, float(lambda_dfl), float(lambda_cls), _p(dpreds), _p(out), _p(ws), _p(grad_scale), _stream(preds))
     return out, dpreds, ws
 
 

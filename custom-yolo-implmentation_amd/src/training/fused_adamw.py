@@ -33,6 +33,40 @@ def _loc(t):
     return t._local_tensor if isinstance(t, DTensor) else t
 
 
+class DeviceGradScaler:
+    """torch.amp.GradScaler's state and rules (defaults: init_scale 65536, growth 2, backoff 0.5, interval 2000 -- what the
+    reference constructs, src/training/train_model.py:195-208) held in device memory, for a training step that never
+    returns to the host: `scale` multiplies the loss gradient inside the loss kernel (functions.LOSS_SCALE), `HipAdamW.step`
+    with `optimizer.device_amp = this` checks every gradient for inf / nan, skips or applies the unscaled update and
+    updates the scale (csrc/optim.hip: yolo_adamw_amp_step).  One optimizer with ONE parameter group per scaler."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0], dtype=torch.float32, device=device)   # scale, found_inf, last found_inf
+        self.tracker = torch.zeros(1, dtype=torch.int32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    @property
+    def scale(self):
+        """fp32 device scalar (a view: the kernels update it in place)."""
+        return self.state[0:1]
+
+    def get_scale(self):
+        return float(self.state[0])                 # host sync: for logging / tests only
+
+    def last_step_skipped(self):
+        return bool(self.state[2] != 0)             # host sync: for logging / tests only
+
+    def state_dict(self):
+        return dict(scale=self.get_scale(), growth_tracker=int(self.tracker), growth_factor=self.growth_factor,
+                    backoff_factor=self.backoff_factor, growth_interval=self.growth_interval)
+
+    def load_state_dict(self, sd):
+        self.state[0] = float(sd["scale"])
+        self.tracker.fill_(int(sd.get("growth_tracker", sd.get("_growth_tracker", 0))))
+        self.growth_factor, self.backoff_factor = sd["growth_factor"], sd["backoff_factor"]
+        self.growth_interval = sd["growth_interval"]
+
+
 class HipAdamW(torch.optim.Optimizer):
     _step_supports_amp_scaling = True      # GradScaler hands over grad_scale / found_inf instead of unscaling itself
 
@@ -154,6 +188,12 @@ class HipAdamW(torch.optim.Optimizer):
                 self.sync_hyper()
             elif plan["hyper_host"] is None:
                 raise RuntimeError("HipAdamW: run one eager step (or sync_hyper()) before capturing a graph")
+            amp = getattr(self, "device_amp", None)
+            if amp is not None:     # fp16 loss scaling kept on the device (DeviceGradScaler): found_inf, step, scale update
+                lib.call("yolo_adamw_amp_step", _p(plan["jobs_dev"]), plan["njobs"], plan["nchunks"], _p(plan["hyper"]),
+                         _p(plan["step"]), _p(amp.state), _p(amp.tracker), float(amp.growth_factor), float(amp.backoff_factor),
+                         int(amp.growth_interval), _stream(_loc(params[0])))
+                continue
             lib.call("yolo_adamw_step", _p(plan["jobs_dev"]), plan["njobs"], plan["nchunks"], _p(plan["hyper"]),
                      _p(plan["step"]), _p(getattr(self, "grad_scale", None)), _p(getattr(self, "found_inf", None)),
                      _stream(_loc(params[0])))      # GradScaler sets the two attributes around step() and deletes them after

@@ -144,6 +144,15 @@ class TrainStepRunner:
             stages = [self.params]
         self.buckets = GradBuckets(stages, grad_comm_dtype) if self.comm else None
         self.avg_in_collective = self.comm and dist.get_backend() == "nccl"       # gloo has no AVG
+        # fp16: dynamic loss scaling kept on the device (no GradScaler round trips: the step stays capturable)
+        self.amp = None
+        if precision == "float16":
+            from src.training.fused_adamw import DeviceGradScaler, HipAdamW
+            if not isinstance(optimizer, HipAdamW) or len(optimizer.param_groups) != 1:
+                raise RuntimeError("TrainStepRunner(precision='float16') needs HipAdamW with one parameter group: the loss "
+                                   "scale, the overflow check and the skipped / unscaled update run on the device")
+            self.amp = getattr(optimizer, "device_amp", None) or DeviceGradScaler(self.params[0].device)
+            optimizer.device_amp = self.amp
         self.graph = None
         self.graph_b = None                     # staged: backward of the backbone + its pack
         self.graph2 = None                      # comm: unpack + optimizer, replayed after the all-reduces
@@ -172,10 +181,12 @@ class TrainStepRunner:
                 return cut["leaf"]
             self.model.stage_cut = at_cut
         F_.LAZY_WGRAD_JOIN = self._lazy(dev)
+        F_.LOSS_SCALE = self.amp.scale if self.amp is not None else None
         try:
             with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                 preds, anchors, strides = self.model(images)
                 loss, ld = self.criterion(preds, packed, anchors, strides)
+            F_.LOSS_SCALE = None
             # the loss tensor is the fused loss node's own output: the seed of backward() (ones) reaches it unchanged
             F_.UNIT_LOSS_SEED = type(loss.grad_fn).__name__ == "DflQflLossBackward" and os.environ.get("YOLO_UNIT_SEED", "1") == "1"
             loss.backward()
@@ -187,6 +198,7 @@ class TrainStepRunner:
             raise
         finally:
             F_.UNIT_LOSS_SEED = False
+            F_.LOSS_SCALE = None
             if self.staged:
                 self.model.stage_cut = None
             if not self.staged:
@@ -245,20 +257,56 @@ class TrainStepRunner:
         self.optimizer.step()
         return loss, ld
 
+    def _probe_accumulators(self):
+        """Hooks on every parameter's AccumulateGrad node that note the stream the node runs on (the engine makes a node's
+        own stream current around it).  Returns a function: number of parameters whose node ran on another stream than the
+        current one at the time of THIS call; the hooks are removed by it."""
+        want = torch.cuda.current_stream().cuda_stream
+        seen, handles, nodes = [], [], []
+        for p in self.params:
+            node = p.view_as(p).grad_fn.next_functions[0][0]        # the (cached) AccumulateGrad node of the leaf
+            if node is None:
+                continue
+            nodes.append(node)                                      # alive until the step has run: the step uses THESE nodes
+            handles.append(node.register_hook(lambda *_: seen.append(torch.cuda.current_stream().cuda_stream)))
+
+        def result():
+            for h in handles:
+                h.remove()
+            nodes.clear()
+            return sum(1 for st in seen if st != want)
+        return result
+
     # -------------------------------------------------------------------------------------------
     def capture(self, images, packed, warmup=3):
         """Warm up on a side stream (allocator + lazy inits), then capture on static inputs."""
         self.static = (images, packed)
+        self.capture_refused = None
+        foreign = 0
         if not self.use_graph:
             return self
         side = self.stream = F_.step_stream(images.device)      # warm-up and capture on the stream DDP was built on
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for i in range(max(warmup, 1)):
+                probe = self._probe_accumulators() if i == 0 else None
                 _, ld = self._eager_step(images, packed)
                 self.warm_scalars = ld._scalars         # the loss scalars of the last warm-up step (a real step)
+                if probe is not None:
+                    foreign = probe()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if foreign:
+            # autograd runs a parameter's AccumulateGrad node on the stream the node was CREATED on.  Somebody keeps nodes
+            # alive that were created elsewhere (a DistributedDataParallel built on the default stream does): they would
+            # drag that stream into the capture and hipStreamEndCapture dies (tools/capture_probe.py).  Measured on this
+            # very step, not assumed from a flag: stay on the eager step.
+            import warnings
+            warnings.warn(f"TrainStepRunner: {foreign} parameter gradients are accumulated on a stream other than the step "
+                          "stream (AccumulateGrad nodes created there are kept alive, e.g. by a DistributedDataParallel built "
+                          "on the default stream): the step is NOT captured, eager steps instead", stacklevel=2)
+            self.capture_refused = "accumulate-grad nodes on a foreign stream"
+            return self
         capturable = all(g.get("capturable", False) for g in self.optimizer.param_groups)
         want_opt = not self.comm and capturable
         self.optimizer.zero_grad(set_to_none=True)

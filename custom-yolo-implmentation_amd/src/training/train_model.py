@@ -73,7 +73,9 @@ class CapturedTraining:
     The first fitting batch is stepped eagerly (the capture's warm-up).  Whether a batch fits the captured buffers
     (batch size, resolution, box capacity) is decided COLLECTIVELY (all-reduce MIN of a host flag over a gloo side
     group): all ranks replay or all ranks step eagerly, with the same buckets and reduction either way.  Needs a
-    capturable optimizer and no GradScaler (bf16 / fp32)."""
+    capturable optimizer.  float16: no torch GradScaler on this route -- the loss scale, the overflow check, the skipped or
+    unscaled update and the scale's growth / backoff (GradScaler's rules and defaults, reference :195-208,247-253) run on the
+    device inside the captured step (`DeviceGradScaler`, needs `HipAdamW`)."""
 
     def __init__(self, model, criterion, optimizer, precision, grad_compress=None):
         import torch.distributed as dist
@@ -87,11 +89,13 @@ class CapturedTraining:
         self.runner, self.dirty, self.captured = None, False, False
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.flag_group = None
-        # a wrapper built elsewhere on the default stream cannot be captured (see prepare_ddp_model): eager loop then
-        self.usable = (not isinstance(model, DDP) or getattr(model, "captured_ok", False)) and \
-            precision in ("bfloat16", "float32") and \
+        # (a wrapper built elsewhere on the default stream cannot be captured -- see prepare_ddp_model; TrainStepRunner.capture
+        # measures that on its warm-up step and keeps stepping eagerly then: no flag to trust)
+        from src.training.fused_adamw import HipAdamW
+        self.usable = precision in ("bfloat16", "float32", "float16") and \
             all(g.get("capturable", False) for g in optimizer.param_groups) and \
-            all(type(p) is torch.nn.Parameter and p.is_cuda for p in self.inner.parameters())
+            all(type(p) is torch.nn.Parameter and p.is_cuda for p in self.inner.parameters()) and \
+            (precision != "float16" or (isinstance(optimizer, HipAdamW) and len(optimizer.param_groups) == 1))
 
     def _all_fit(self, fits):
         """AND of the ranks' `fits` flags (host side: no device sync)."""
@@ -205,14 +209,17 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, init
     one GPU, plain parameters, capturable optimizer), True = also with more than one rank, False = the reference's eager
     loop.  `grad_compress`: None = fp32 gradient exchange (the reference's), "bf16" = bf16 buckets in the captured step."""
     use_amp = precision in ("float16", "bfloat16")
-    scaler = _make_scaler(precision, distributed_mode, device, rank) if use_amp else None
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     want_captured = captured_step is True or (captured_step is None and world == 1)
     captured = CapturedTraining(model, criterion, optimizer, precision, grad_compress=grad_compress) \
-        if (want_captured and device != "cpu" and distributed_mode == "ddp" and scaler is None) else None
+        if (want_captured and device != "cpu" and distributed_mode == "ddp") else None
     if captured is not None and not captured.usable:
         captured = None
+    # the captured route scales fp16 losses on the device; the eager loop uses torch's (Sharded)GradScaler like the reference
+    scaler = _make_scaler(precision, distributed_mode, device, rank) if (use_amp and captured is None) else None
+    if captured is not None and precision == "float16" and rank == 0:
+        print("[INFO] float16: dynamic loss scaling runs on the device inside the captured step (GradScaler's rules)")
     autocast_kw = dict(device_type="cpu" if device == "cpu" else "cuda",
                        dtype=torch.bfloat16 if precision == "bfloat16" else torch.float16,
                        enabled=(distributed_mode == "ddp" and use_amp))       # FSDP modes rely on their MP policy

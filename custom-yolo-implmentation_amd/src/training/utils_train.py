@@ -41,17 +41,20 @@ def get_optimizer(model: nn.Module, lr: float, weight_decay: float, patience: in
     return opt, optim.lr_scheduler.ReduceLROnPlateau(opt, patience=patience, factor=factor)
 
 
-_WRAPPER_SEGMENTS = ("module.", "_fsdp_wrapped_module.", "_orig_mod.", "_checkpoint_wrapped_module.")
+_WRAPPER_SEGMENT = __import__("re").compile(r"(^|\.)(?:module|_fsdp_wrapped_module|_orig_mod|_checkpoint_wrapped_module)\.")
 
 
 def canonical_state_dict(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Keys as the bare `Model` names them: wrapper segments that DDP ("module."), FSDP1, torch.compile or
-    activation checkpointing insert are removed, so a checkpoint written under one wrapper loads under any other
-    (the reference's DDP checkpoints carry "module." and fail in its own `Model.load_weights`)."""
+    activation checkpointing insert are removed (whole dotted segments only), so a checkpoint written under one wrapper
+    loads under any other (the reference's DDP checkpoints carry "module." and fail in its own `Model.load_weights`)."""
     out = {}
     for k, v in state.items():
-        for seg in _WRAPPER_SEGMENTS:
-            k = k.replace(seg, "")
+        while True:
+            k2 = _WRAPPER_SEGMENT.sub(r"\1", k)
+            if k2 == k:
+                break
+            k = k2
         out[k] = v
     return out
 
@@ -124,7 +127,8 @@ def prepare_ddp_model(model: nn.Module, device_id: int, config: Dict[str, Union[
         return DDP(model, device_ids=None, find_unused_parameters=unused)
     # Built on the step stream: DDP keeps each parameter's AccumulateGrad node alive, and autograd runs such a node on
     # the stream it was created on -- on the default stream that would pull the default stream into the captured step
-    # (hipStreamEndCapture then dies: tools/capture_probe.py).  `captured_ok` tells CapturedTraining so.
+    # (hipStreamEndCapture then dies: tools/capture_probe.py).  TrainStepRunner.capture checks the streams of the nodes on its
+    # warm-up step and refuses to capture otherwise; `captured_ok` only documents that this wrapper was built the right way.
     from src.hipops import functions as F_
     st = F_.step_stream(torch.device("cuda", device_id))
     st.wait_stream(torch.cuda.current_stream())

@@ -77,6 +77,8 @@ int yolo_adamw_job_fill(void* jobs_host, int index, void* p, int p_dtype, const 
 long yolo_adamw_jobs_finalize(void* jobs_host, int njobs);
 int yolo_adamw_jobs_set_grads(void* jobs_host, int njobs, const void* const* grads);
 int yolo_adamw_step(const void* jobs_dev, int njobs, long nchunks, const double* hyper, float* step, const float* grad_scale, const float* found_inf, hipStream_t st);
+/* fp16 dynamic loss scaling without the host (GradScaler's scale / step / update, train_model.py:195-208,247-253): amp_state = fp32 [scale, found_inf (0 on entry), last_found_inf]; the gradients carry the factor `scale` (see yolo_loss_dfl_qfl's grad_scale) */
+int yolo_adamw_amp_step(const void* jobs_dev, int njobs, long nchunks, const double* hyper, float* step, float* amp_state, int* growth_tracker, float growth_factor, float backoff_factor, int growth_interval, hipStream_t st);
 /* ---- gradient exchange: pack / unpack every parameter gradient into / out of the flat communication buffers in one launch
    (DistributedDataParallel's bucket copies: src/training/utils_train.py:190); jobs: device copy of a host table of
    yolo_copy_job_bytes() records, dst = src * scale with a dtype cast */
@@ -158,7 +160,7 @@ int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* 
 
 /* ---- YoloDFLQFLoss forward+gradient (losses.py:93-281) */
 size_t yolo_loss_workspace_bytes(int N, int A, int G);
-int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A, const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl, float lambda_cls, void* dpreds, float* out, void* workspace, hipStream_t st);
+int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A, const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl, float lambda_cls, void* dpreds, float* out, void* workspace, const float* grad_scale, hipStream_t st);
 
 /* the reference's module-level loss helpers as stand-alone differentiable fp32 ops (notebook API; the training step uses
    the fused pass above): bbox_iou (losses.py:9-40, incl. the b1_y2 slip), quality_focal_loss (:46-57),

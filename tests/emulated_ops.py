@@ -297,7 +297,7 @@ def attn_bwd(qkv, o, d_o, d_vp, lse, heads, dk, dh, scale):
     return _nhwc(g.to(qkv.dtype))
 
 
-def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_dfl, lambda_cls, want_grad):
+def loss_fwd_bwd(preds, anchors, strides, gt, gt_off, gt_img, n_gt, nc, lambda_dfl, lambda_cls, want_grad, grad_scale=None):
     offs = gt_off.tolist()
     gts = [gt[offs[i]:offs[i + 1]].reshape(-1, 5) for i in range(preds.shape[0])]
     p = preds.detach().clone().requires_grad_(True)

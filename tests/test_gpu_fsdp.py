@@ -159,12 +159,22 @@ def test_fsdp2_step_uses_the_one_launch_optimizer_and_no_cast_kernels(pg):
         a, b = p1.full_tensor(), p2.full_tensor()
         assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(b.abs().max()), k
 
-    # no cast launches for gamma / beta / running statistics: count ATen copy kernels of a forward + backward
+    # no cast launches for gamma / beta / running statistics: ATen dtype conversions issued from inside the fused block's
+    # forward / backward (FSDP2's own per-parameter copies, outside the blocks, are not counted)
     from torch.profiler import ProfilerActivity, profile
     m1.zero_grad(set_to_none=True)
     with profile(activities=[ProfilerActivity.CPU]) as prof:
         m1(img)[0].float().square().mean().backward()
-    n_bn = sum(1 for m in m1.modules() if type(m).__name__ == "Conv")
-    copies = sum(e.count for e in prof.key_averages() if e.key in ("aten::_to_copy", "aten::copy_"))
-    print(f"\n[fsdp2 bf16 step] {n_bn} Conv blocks, {copies} aten copy / cast calls in one forward + backward")
-    assert copies < 2 * n_bn, copies          # round 2: eight casts per block (gamma, beta, two buffers there and back, two gradients)
+
+    def inside_block(e):
+        while e is not None:
+            if e.name.startswith("ConvBnAct"):
+                return True
+            e = e.cpu_parent
+        return False
+    casts = sum(1 for e in prof.events() if e.name == "aten::_to_copy" and inside_block(e))
+    blocks = [m for m in m1.modules() if type(m).__name__ == "Conv"]
+    n_dw = sum(1 for m in blocks if m._dw)
+    print(f"\n[fsdp2 bf16 step] {len(blocks)} Conv blocks ({n_dw} depthwise): {casts} dtype-conversion launches inside the blocks "
+          f"in one forward + backward (round 2: eight per block)")
+    assert casts <= 4 * n_dw, casts            # only the depthwise taps (fp32 [C][9] tables for the strip kernels) are converted

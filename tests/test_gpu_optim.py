@@ -109,3 +109,64 @@ def test_inside_a_captured_graph_with_lr_change_between_replays():
     for x, y in zip(a, b):
         assert torch.allclose(x, y, rtol=5e-6, atol=5e-7), float((x - y).abs().max())
     assert float(oa.state[a[0]]["step"]) == 5
+
+
+def test_device_grad_scaler_follows_torch_gradscaler_step_for_step():
+    """DeviceGradScaler + HipAdamW (found_inf, skipped / unscaled update and the scale's growth / backoff all on the device,
+    four launches: csrc/optim.hip yolo_adamw_amp_step) against torch.amp.GradScaler + torch.optim.AdamW on the same scaled
+    gradients: finite, overflow (inf), finite, nan, finite, finite with growth_interval 2 -- parameters and the scale
+    after every step (reference protocol: src/training/train_model.py:195-208,247-253)."""
+    from src.training.fused_adamw import DeviceGradScaler, HipAdamW
+    a, b = _params(3), _params(3)
+    oa = HipAdamW(a, lr=1e-3, weight_decay=1e-2)
+    ob = torch.optim.AdamW(b, lr=1e-3, weight_decay=1e-2)
+    mine = DeviceGradScaler("cuda", init_scale=4096.0, growth_interval=2)
+    oa.device_amp = mine
+    ref = torch.amp.GradScaler("cuda", init_scale=4096.0, growth_interval=2)
+    ref.scale(torch.zeros(1, device="cuda"))                       # lazy init of torch's scale tensor
+    poison = {1: float("inf"), 3: float("nan")}
+    skipped = []
+    for s in range(6):
+        sc = ref.get_scale()
+        assert mine.get_scale() == sc, (s, mine.get_scale(), sc)
+        _set_grads(a, 40 + s, sc), _set_grads(b, 40 + s, sc)        # gradients of the scaled loss
+        if s in poison:
+            a[2].grad[3] = poison[s]
+            b[2].grad[3] = poison[s]
+        oa.step()
+        ref.step(ob)
+        ref.update()
+        skipped.append(mine.last_step_skipped())
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-6), (s, float((x - y).abs().max()))
+    assert skipped == [False, True, False, True, False, False]
+    assert mine.get_scale() == ref.get_scale() == 2048.0           # 4096 -> 2048 (inf) -> 1024 (nan) -> 2048 (two good steps)
+    assert float(oa.state[a[0]]["step"]) == 4 == float(ob.state[b[0]]["step"])
+    sd = mine.state_dict()
+    again = DeviceGradScaler("cuda")
+    again.load_state_dict(sd)
+    assert again.get_scale() == 2048.0 and int(again.tracker) == int(mine.tracker)
+
+
+def test_loss_kernel_applies_the_scale_in_fp32_before_rounding():
+    """fp16 predictions: gradients of ~1e-6 are subnormal in fp16; scaled by 65536 INSIDE the kernel they keep fp32's
+    precision (scaling the rounded fp16 gradient afterwards, as `scale * loss` through a post-pass did, loses them)."""
+    from src.hipops import ops
+    from src.model.losses import PackedTargets
+    g = torch.Generator().manual_seed(5)
+    n, nc, a = 2, 80, 2100
+    preds = (torch.randn(n, 64 + nc, a, generator=g) * 0.5).half().cuda()
+    from src.utils.model_utils import make_anchors_cached
+    anchors, strides = make_anchors_cached(((40, 40), (20, 20), (10, 10)), (8.0, 16.0, 32.0), torch.float16, torch.device("cuda", 0))
+    gts = [torch.tensor([[100., 120., 60., 40., 3.]]).cuda(), torch.tensor([[200., 80., 30., 90., 7.], [50., 50., 20., 20., 1.]]).cuda()]
+    pk = PackedTargets(gts, "cuda")
+    scale = torch.tensor([65536.0], device="cuda")
+    out1, d1, _ = ops.loss_fwd_bwd(preds, anchors, strides, *pk.as_tuple(), nc, 1.5, 1.0, True)
+    out2, d2, _ = ops.loss_fwd_bwd(preds, anchors, strides, *pk.as_tuple(), nc, 1.5, 1.0, True, scale)
+    out3, d3, _ = ops.loss_fwd_bwd(preds.float(), anchors.float(), strides.float(), *pk.as_tuple(), nc, 1.5, 1.0, True)
+    assert torch.equal(out1, out2)                                  # the loss VALUE is never scaled
+    want = d3 * 65536.0
+    err_in = float((d2.float() - want).abs().max() / want.abs().max())
+    err_post = float((d1.float() * 65536.0 - want).abs().max() / want.abs().max())
+    print(f"\n[fp16 loss scaling] max error vs fp32 gradient: in-kernel {err_in:.2e}, scaled after rounding {err_post:.2e}")
+    assert err_in < 1e-3 and torch.isfinite(d2.float()).all()
