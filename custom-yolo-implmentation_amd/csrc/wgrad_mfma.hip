@@ -31,9 +31,19 @@ template <> struct mm<f16_t> {
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-// LDS row (one pixel) of a T*32-channel tile: pad so that the four pixel rows of a transposing read land on
-// different banks (row stride in banks mod 64: 32 ch -> 16, 64 -> 36, 96 -> 48, 128 -> 8)
-constexpr int ldc_of(int t) { return t == 2 ? 72 : t == 4 ? 144 : t * 32; }
+// LDS image.  ds_read_b64_tr_b16 is served in two groups of 32 lanes, bank = (byte address / 4) mod 64
+// (MI355X_MICROARCH.md, LDS).  In a transposing fragment read the 32 lanes of a group cover EIGHT pixel rows x 32 bytes (one
+// 16-channel block): conflict-free iff the eight rows start on eight different multiples of 8 banks.  Two choices make that
+// hold for every read of the kernel:
+//  * row stride = 32*t + 16 elements = 8 * (2t + 1) banks, an ODD multiple of 8: rows r .. r+7 then start on 8 different
+//    multiples of 8 banks (round 2's strides -- 16, 36, 48, 72 banks -- put them two to four deep: 38 % of the kernel's LDS
+//    cycles were conflict cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE);
+//  * the eight rows of a read are made two runs of four rows 12 apart (12 = 4 mod 8) or one run of eight: dY pixel j of the
+//    4 x 8 patch sits in row (j&3) + 4*((j>>3)&1) + 8*((j>>2)&1) + 16*(j>>4) (a read takes pixels 8g+q and 8(g+1)+q, q = 0..3);
+//    the X patch is stored 12 pixels wide (PWL), and for stride 2 as four parity planes (row parity, column parity) so
+//    that the pixels two apart which a stride-2 tap reads are neighbours in their plane.
+constexpr int ldc_of(int t) { return t * 32 + 16; }
+constexpr int PWL = 12;                                      // LDS width (pixels) of the X patch / of one parity plane
 
 struct WgArgs {
     int N, H, W, Cin, ldx, OH, OW, Cout, ldy, Kpad;
@@ -59,21 +69,27 @@ __device__ __forceinline__ typename mm<T>::frag tr_frag(const T* p_lo, const T* 
     return __builtin_bit_cast(typename mm<T>::frag, both);
 }
 
-template <typename T, int KS, int S, int TCO, int TCI>
+// PF = patches in flight per workgroup.  A layer with at most one workgroup per CU (every 20x20 / 40x40 map) is bound by the
+// round trip of its patch loads -- 1.5-2 us each from cold caches, against ~0.4 us of LDS reads + MFMAs per patch -- so the
+// small layers keep FOUR patches in flight in registers (12-24 registers each); the big layers, whose second workgroup per CU
+// already hides the latency, keep one (and their 2 workgroups per CU).
+template <typename T, int KS, int S, int TCO, int TCI, int PF>
 __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ x, const T* __restrict__ dy,
                                                 float* __restrict__ dwp) {
     constexpr int PAD = KS / 2;
     constexpr int PH = 3 * S + KS, PW = 7 * S + KS;          // X patch (with halo) for 4 x 8 outputs
-    // stride 2 spreads the four patch columns of a transposing read two pixels apart: 32- and 96-channel rows then put them
-    // on the same banks four ways (SQ_LDS_BANK_CONFLICT), 8 elements of padding bring it back to the two-way floor of this mapping
-    constexpr int LDY = ldc_of(TCO), LDX = ldc_of(TCI) + ((S == 2 && (TCI & 1)) ? 8 : 0);
+    constexpr int LDY = ldc_of(TCO), LDX = ldc_of(TCI);
+    constexpr int SUB = ((PH + 1) / 2) * PWL;                 // stride 2: LDS rows of one parity plane
+    constexpr int XROWS = S == 1 ? PH * PWL : 4 * SUB;        // LDS rows of the X image
     constexpr int CPY = TCO * 4, CPX = TCI * 4;               // 16-byte chunks per pixel (dY / X tile)
     constexpr int YCH = 32 * CPY, YR = (YCH + 255) / 256;     // dY chunks per patch / per thread
     constexpr int XCH = PH * PW * CPX;                        // 16-byte chunks in the X patch
     constexpr int XR = (XCH + 255) / 256;                     // chunks per thread
     constexpr int NT = KS * KS;
+    static_assert(PW <= PWL || S == 2, "X patch wider than its LDS image");
+    static_assert(S == 1 || (PW + 1) / 2 <= PWL, "parity plane wider than its LDS image");
     __shared__ __attribute__((aligned(16))) T ys[32 * LDY];
-    __shared__ __attribute__((aligned(16))) T xs[PH * PW * LDX];
+    __shared__ __attribute__((aligned(16))) T xs[XROWS * LDX];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wi = wave & 1;
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x) - xshift, 0, (a.N * a.H * a.W * a.ldx + xshift) * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy), 0, a.N * a.OH * a.OW * a.ldy * 2, 0x00020000);
-    int yrow[YR], ycol[YR], yvoff[YR];                       // dY chunk: pixel (row, col) of the 4x8 patch + channel chunk
+    int yrow[YR], ycol[YR], yvoff[YR], ylds[YR];             // dY chunk: pixel (row, col) of the 4x8 patch + channel chunk
 #pragma unroll
     for (int r = 0; r < YR; ++r) {
         const int id = tid + 256 * r;
@@ -110,8 +126,9 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         yrow[r] = j >> 3;
         ycol[r] = j & 7;
         yvoff[r] = (id < YCH && bco + ch < a.Cout) ? ((yrow[r] * a.OW + ycol[r]) * a.ldy + bco + ch) * 2 : (int)0x80000000;
+        ylds[r] = id < YCH ? ((j & 3) + 4 * ((j >> 3) & 1) + 8 * ((j >> 2) & 1) + 16 * (j >> 4)) * LDY + ch : -1;
     }
-    int xpr[XR], xpc[XR], xvoff[XR];
+    int xpr[XR], xpc[XR], xvoff[XR], xlds[XR];
 #pragma unroll
     for (int r = 0; r < XR; ++r) {
         const int id = tid + 256 * r;
@@ -119,6 +136,9 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         xpr[r] = px / PW;
         xpc[r] = px - xpr[r] * PW;
         xvoff[r] = (id < XCH && bci + ch < a.Cin) ? ((xpr[r] * a.W + xpc[r]) * a.ldx + bci + ch) * 2 : (int)0x80000000;
+        const int row = S == 1 ? xpr[r] * PWL + xpc[r]
+                               : ((xpr[r] & 1) * 2 + (xpc[r] & 1)) * SUB + (xpr[r] >> 1) * PWL + (xpc[r] >> 1);
+        xlds[r] = id < XCH ? row * LDX + ch : -1;
     }
     int pn, pbh, pbw;                                        // coordinates of the patch gload fetches next
     {
@@ -128,8 +148,8 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         pbh = rem / a.pbw;
         pbw = rem - pbh * a.pbw;
     }
-    uint4 ry[YR], rx[XR];
-    auto gload = [&]() {
+    uint4 ry[PF][YR], rx[PF][XR];
+    auto gload = [&](uint4 (&ry_)[YR], uint4 (&rx_)[XR]) {
         const int oh0 = pbh * 4, ow0 = pbw * 8;
         const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
         const int ysoff = ((pn * a.OH + oh0) * a.OW + ow0) * a.ldy * 2;
@@ -137,61 +157,66 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         for (int r = 0; r < YR; ++r) {
             const bool ok = oh0 + yrow[r] < a.OH && ow0 + ycol[r] < a.OW;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok ? yvoff[r] : (int)0x80000000, ysoff, 0);
-            ry[r] = make_uint4(v.x, v.y, v.z, v.w);
+            ry_[r] = make_uint4(v.x, v.y, v.z, v.w);
         }
         const int xsoff = (((pn * a.H + ih0) * a.W + iw0) * a.ldx + xshift) * 2;
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
             const bool ok = (unsigned)(ih0 + xpr[r]) < (unsigned)a.H && (unsigned)(iw0 + xpc[r]) < (unsigned)a.W;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvoff[r] : (int)0x80000000, xsoff, 0);
-            rx[r] = make_uint4(v.x, v.y, v.z, v.w);
+            rx_[r] = make_uint4(v.x, v.y, v.z, v.w);
         }
         if (++pbw == a.pbw) {
             pbw = 0;
             if (++pbh == a.pbh) { pbh = 0; ++pn; }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](const uint4 (&ry_)[YR], const uint4 (&rx_)[XR]) {
 #pragma unroll
-        for (int r = 0; r < YR; ++r) {
-            const int id = tid + 256 * r;
-            if (id < YCH) *reinterpret_cast<uint4*>(ys + (id / CPY) * LDY + (id % CPY) * 8) = ry[r];
-        }
+        for (int r = 0; r < YR; ++r)
+            if (ylds[r] >= 0) *reinterpret_cast<uint4*>(ys + ylds[r]) = ry_[r];
 #pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int id = tid + 256 * r;
-            if (id < XCH) *reinterpret_cast<uint4*>(xs + (id / CPX) * LDX + (id % CPX) * 8) = rx[r];
-        }
+        for (int r = 0; r < XR; ++r)
+            if (xlds[r] >= 0) *reinterpret_cast<uint4*>(xs + xlds[r]) = rx_[r];
     };
 
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
-    if (p_begin < p_end) gload();
-    for (long pi = p_begin; pi < p_end; ++pi) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (pi + 1 < p_end) gload();
-        // A fragments (dY^T): rows = co, k = patch pixel 8g + j  ->  LDS pixel rows 8g+q and 8g+4+q
+    // dY^T fragment rows: pixels 8g+q (lo) and 8g+4+q (hi) -> LDS rows q + 4*(g&1) + 16*(g>>1) and that + 8
+    const T* ya = ys + (q + 4 * (g & 1) + 16 * (g >> 1)) * LDY + wc * TCO * 16 + c4;
+    auto compute = [&]() {
+        // A fragments (dY^T): rows = co, k = patch pixel 8g + j
         typename mm<T>::frag fa[TCO];
 #pragma unroll
-        for (int i = 0; i < TCO; ++i) {
-            const T* p = ys + (8 * g + q) * LDY + (wc * TCO + i) * 16 + c4;
-            fa[i] = tr_frag<T>(p, p + 4 * LDY);
-        }
+        for (int i = 0; i < TCO; ++i) fa[i] = tr_frag<T>(ya + i * 16, ya + i * 16 + 8 * LDY);
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
                 // output pixel (row g, col q | q+4) reads X patch pixel (g*S + kh, col*S + kw)
-                const T* base = xs + ((g * S + kh) * PW + q * S + kw) * LDX + c4;
+                const int row = S == 1 ? (g + kh) * PWL + q + kw
+                                       : ((kh & 1) * 2 + (kw & 1)) * SUB + (g + (kh >> 1)) * PWL + q + (kw >> 1);
+                const T* base = xs + row * LDX + wi * TCI * 16 + c4;
 #pragma unroll
                 for (int j = 0; j < TCI; ++j) {
-                    const T* p = base + (wi * TCI + j) * 16;
-                    typename mm<T>::frag fb = tr_frag<T>(p, p + 4 * S * LDX);
+                    typename mm<T>::frag fb = tr_frag<T>(base + j * 16, base + j * 16 + 4 * LDX);
 #pragma unroll
                     for (int i = 0; i < TCO; ++i) acc[kh * KS + kw][i][j] = mm<T>::mma(fa[i], fb, acc[kh * KS + kw][i][j]);
                 }
             }
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < PF; ++s2)
+        if (p_begin + s2 < p_end) gload(ry[s2], rx[s2]);
+    for (long pi = p_begin; pi < p_end; pi += PF) {
+#pragma unroll
+        for (int s2 = 0; s2 < PF; ++s2) {
+            if (pi + s2 >= p_end) break;
+            __syncthreads();
+            lstore(ry[s2], rx[s2]);
+            __syncthreads();
+            if (pi + s2 + PF < p_end) gload(ry[s2], rx[s2]);
+            compute();
+        }
     }
     // Partial sums leave as a raw register image: part[slab][tile][wave][tap][i][j][lane] is the lane's float4 accumulator
     // (rows co = g*4 + r, column ci = lane & 15 of the 16x16 block (i, j)) -- one fully coalesced 1 KB store per accumulator
@@ -261,7 +286,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
-struct WgPlan { int to, ti, cot, cit, nslab; long per_slab; };
+struct WgPlan { int to, ti, cot, cit, nslab, pf; long per_slab; };
 
 template <typename TO>
 void launch_reduce(const float* part, const WgPlan& p, int Cout, int Cin, int NT, void* dw, hipStream_t st) {
@@ -278,12 +303,13 @@ void launch_reduce(const float* part, const WgPlan& p, int Cout, int Cin, int NT
 
 // Plan overrides (tile, workgroup count), 0 = automatic.  Read ONCE per process from YOLO_WG_TUNE ("to,ti,blocks,min_per")
 // and YOLO_WG_BLOCKS; tools/wg_tune.py and the plan-forcing parity tests change them through yolo_wgrad_tune_set.
-struct WgTune { int to, ti, blocks, min_per; long all_blocks; };
+struct WgTune { int to, ti, blocks, min_per; long all_blocks; int pf; };
 WgTune& wg_tune() {
     static WgTune t = [] {
-        WgTune v{0, 0, 0, 0, 0};
+        WgTune v{0, 0, 0, 0, 0, 0};
         if (const char* e = getenv("YOLO_WG_TUNE")) sscanf(e, "%d,%d,%d,%d", &v.to, &v.ti, &v.blocks, &v.min_per);
         if (const char* e2 = getenv("YOLO_WG_BLOCKS")) v.all_blocks = atol(e2);
+        if (const char* e3 = getenv("YOLO_WG_PF")) v.pf = atoi(e3);         // 1 / 4: force the prefetch depth (A/B runs)
         return v;
     }();
     return t;
@@ -347,6 +373,9 @@ WgPlan make_plan(const WgArgs& a, int k) {
     if (want < 1) want = 1;
     p.per_slab = (a.npatch + want - 1) / want;
     p.nslab = (int)((a.npatch + p.per_slab - 1) / p.per_slab);
+    // at most one workgroup per CU: nothing else hides the patch loads' latency -> four patches in flight (see k_wgrad2)
+    p.pf = (long)p.nslab * p.cot * p.cit <= 320 ? 4 : 1;
+    if (tu.pf == 1 || tu.pf == 4) p.pf = tu.pf;
     return p;
 }
 
@@ -357,8 +386,11 @@ void launch(const WgArgs& a, const WgPlan& p, const void* x, const void* dy, flo
     b.cot = p.cot; b.cit = p.cit;
     static const int xcd = [] { const char* e = getenv("YOLO_WG_XCD"); return e ? atoi(e) : 1; }();
     b.xcd = xcd;
-    hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI>), dim3((unsigned)(p.cot * p.cit * p.nslab)), dim3(256), 0, st, b, (const T*)x,
-                       (const T*)dy, part);
+    const dim3 grid((unsigned)(p.cot * p.cit * p.nslab));
+    if (p.pf == 4)
+        hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI, 4>), grid, dim3(256), 0, st, b, (const T*)x, (const T*)dy, part);
+    else
+        hipLaunchKernelGGL((k_wgrad2<T, KS, S, TCO, TCI, 1>), grid, dim3(256), 0, st, b, (const T*)x, (const T*)dy, part);
 }
 
 template <typename T, int KS, int S>
@@ -402,6 +434,13 @@ extern "C" int yolo_wgrad_tune_set(int to, int ti, int blocks, int min_per) {
     return YOLO_OK;
 }
 
+// test / tuning override of the patches-in-flight variant: 0 = automatic, 1 or 4
+extern "C" int yolo_wgrad_tune_pf(int pf) {
+    if (pf != 0 && pf != 1 && pf != 4) return YOLO_ERR_ARG;
+    wg_tune().pf = pf;
+    return YOLO_OK;
+}
+
 // fp32 elements of partial-sum scratch the launch below writes: one register image of every (co, ci) tile per slab
 long mfma_wgrad2_ws_elems(int Kpad, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k) {
     WgArgs a = make_args(0, 0, Kpad, N, H, W, Cin, OH, OW, Cout);
@@ -414,7 +453,7 @@ long mfma_wgrad2_plan(int Kpad, int N, int H, int W, int Cin, int OH, int OW, in
     WgArgs a = make_args(0, 0, Kpad, N, H, W, Cin, OH, OW, Cout);
     if (a.npatch == 0) return 0;
     const WgPlan p = make_plan(a, k);
-    return p.to * 1000000L + p.ti * 100000L + p.nslab;
+    return p.pf * 10000000L + p.to * 1000000L + p.ti * 100000L + p.nslab;
 }
 
 // part (fp32 scratch of mfma_wgrad2_ws_elems elements, need not be zeroed) <- per-slab partial gradients, then

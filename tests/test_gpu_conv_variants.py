@@ -38,6 +38,7 @@ def _reset_tuning():
     yield
     lib().call("yolo_conv_tune_set", 0, -1, -1, -1, -1, 0, 0, 0)
     lib().call("yolo_wgrad_tune_set", 0, 0, 0, 0)
+    lib().call("yolo_wgrad_tune_pf", 0)
 
 
 def rnd(shape, seed, scale=1.0, dtype=None):
@@ -219,17 +220,26 @@ def test_stride2_dgrad_patch_kernel_f16():
     run_fwd_dgrad_case(3, 72, 96, 84, 100, 3, 2, images=[0, 1, 2], ldx=72 + 32, ldy=96 + 16, stats=False, seed=5, dtype=torch.float16)
 
 
+@pytest.mark.parametrize("pf", [1, 4])          # patches in flight: the big-layer and the small-layer variant of k_wgrad2
 @pytest.mark.parametrize("to,ti", [(1, 1), (1, 2), (2, 1), (2, 2)])
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2)])
-def test_wgrad_3x3_every_tile(to, ti, k, s):
+def test_wgrad_3x3_every_tile(to, ti, k, s, pf):
     lib().call("yolo_wgrad_tune_set", to, ti, 0, 0)
+    lib().call("yolo_wgrad_tune_pf", pf)
+    assert lib().query("yolo_conv2d_wgrad_plan", 3, 37, 41, 72, *ops().conv_out_hw(37, 41, k, s), 88, k, s, lib().BF16) // 10000000 == pf
     run_wgrad_case(3, 72, 88, 37, 41, k, s, ldx=104, ldy=96, seed=to * 4 + ti)
+    if pf == 4:         # a slab of 1, 2, 3, 5 patches: the prefetch ring's prologue / tail shorter than its depth
+        for blocks in (4000, 700):
+            lib().call("yolo_wgrad_tune_set", to, ti, blocks, 1)
+            run_wgrad_case(2, 72, 88, 19, 23, k, s, ldx=104, ldy=96, seed=to * 4 + ti + blocks)
 
 
+@pytest.mark.parametrize("pf", [1, 4])
 @pytest.mark.parametrize("to", [1, 2, 3, 4])
 @pytest.mark.parametrize("ti", [1, 2, 3, 4])
-def test_wgrad_1x1_every_tile(to, ti):
+def test_wgrad_1x1_every_tile(to, ti, pf):
     lib().call("yolo_wgrad_tune_set", to, ti, 0, 0)
+    lib().call("yolo_wgrad_tune_pf", pf)
     run_wgrad_case(3, 136, 120, 37, 41, 1, 1, ldx=160, ldy=128, seed=to * 4 + ti)
 
 
