@@ -69,10 +69,12 @@ __device__ __forceinline__ typename mm<T>::frag tr_frag(const T* p_lo, const T* 
     return __builtin_bit_cast(typename mm<T>::frag, both);
 }
 
-// PF = patches in flight per workgroup.  A layer with at most one workgroup per CU (every 20x20 / 40x40 map) is bound by the
-// round trip of its patch loads -- 1.5-2 us each from cold caches, against ~0.4 us of LDS reads + MFMAs per patch -- so the
-// small layers keep FOUR patches in flight in registers (12-24 registers each); the big layers, whose second workgroup per CU
-// already hides the latency, keep one (and their 2 workgroups per CU).
+// PF = patches in flight per workgroup (registers: 12-24 per patch).  PF = 4 was built for the layers with at most one
+// workgroup per CU (every 20x20 / 40x40 map) on the assumption that they are bound by the round trip of their patch loads.
+// Measured (tools/wg_scan.py, profiles/r3_wgrad_scan.log): they are not -- the marginal cost of a patch is 0.4-0.6 us
+// (3x3) whatever the depth, and ~20 us of every small layer is FIXED: two launches, the partial-matrix store of every
+// workgroup and the reduce pass.  PF = 4 is 5-15 % slower (254 registers, one full drain of the ring per loop trip at the
+// loop header, where the compiler's waitcnt analysis gives up) and is kept only as a tested variant (yolo_wgrad_tune_pf).
 template <typename T, int KS, int S, int TCO, int TCI, int PF>
 __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ x, const T* __restrict__ dy,
                                                 float* __restrict__ dwp) {
@@ -149,20 +151,24 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
         pbw = rem - pbh * a.pbw;
     }
     uint4 ry[PF][YR], rx[PF][XR];
-    auto gload = [&](uint4 (&ry_)[YR], uint4 (&rx_)[XR]) {
+    // `live` false (a slot past the end of the slab): every chunk gets the out-of-range offset -- no memory traffic, zeros
+    // in the registers -- so that each step issues the SAME number of loads and the compiler's s_waitcnt vmcnt(N) in front
+    // of a slot's LDS stores can count the younger slots' loads instead of waiting for all of them (with the loads under a
+    // branch it emitted vmcnt(2..0): the whole ring drained every step, 10-20 % SLOWER than one patch in flight)
+    auto gload = [&](uint4 (&ry_)[YR], uint4 (&rx_)[XR], bool live) {
         const int oh0 = pbh * 4, ow0 = pbw * 8;
         const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
-        const int ysoff = ((pn * a.OH + oh0) * a.OW + ow0) * a.ldy * 2;
+        const int ysoff = live ? ((pn * a.OH + oh0) * a.OW + ow0) * a.ldy * 2 : 0;
 #pragma unroll
         for (int r = 0; r < YR; ++r) {
-            const bool ok = oh0 + yrow[r] < a.OH && ow0 + ycol[r] < a.OW;
+            const bool ok = live && oh0 + yrow[r] < a.OH && ow0 + ycol[r] < a.OW;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok ? yvoff[r] : (int)0x80000000, ysoff, 0);
             ry_[r] = make_uint4(v.x, v.y, v.z, v.w);
         }
-        const int xsoff = (((pn * a.H + ih0) * a.W + iw0) * a.ldx + xshift) * 2;
+        const int xsoff = live ? (((pn * a.H + ih0) * a.W + iw0) * a.ldx + xshift) * 2 : 0;
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
-            const bool ok = (unsigned)(ih0 + xpr[r]) < (unsigned)a.H && (unsigned)(iw0 + xpc[r]) < (unsigned)a.W;
+            const bool ok = live && (unsigned)(ih0 + xpr[r]) < (unsigned)a.H && (unsigned)(iw0 + xpc[r]) < (unsigned)a.W;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvoff[r] : (int)0x80000000, xsoff, 0);
             rx_[r] = make_uint4(v.x, v.y, v.z, v.w);
         }
@@ -184,6 +190,8 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
     // dY^T fragment rows: pixels 8g+q (lo) and 8g+4+q (hi) -> LDS rows q + 4*(g&1) + 16*(g>>1) and that + 8
     const T* ya = ys + (q + 4 * (g & 1) + 16 * (g >> 1)) * LDY + wc * TCO * 16 + c4;
     auto compute = [&]() {
+        // (Issuing all 40 fragment reads of a patch before its first MFMA -- counted lgkmcnt waits, sched_barrier between the
+        // phases -- was measured 4 % SLOWER over the layers of preset s than this interleaved order.)
         // A fragments (dY^T): rows = co, k = patch pixel 8g + j
         typename mm<T>::frag fa[TCO];
 #pragma unroll
@@ -205,8 +213,7 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
             }
     };
 #pragma unroll
-    for (int s2 = 0; s2 < PF; ++s2)
-        if (p_begin + s2 < p_end) gload(ry[s2], rx[s2]);
+    for (int s2 = 0; s2 < PF; ++s2) gload(ry[s2], rx[s2], p_begin + s2 < p_end);
     for (long pi = p_begin; pi < p_end; pi += PF) {
 #pragma unroll
         for (int s2 = 0; s2 < PF; ++s2) {
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256) void k_wgrad2(WgArgs a, const T* __restrict__ 
             __syncthreads();
             lstore(ry[s2], rx[s2]);
             __syncthreads();
-            if (pi + s2 + PF < p_end) gload(ry[s2], rx[s2]);
+            gload(ry[s2], rx[s2], pi + s2 + PF < p_end);
             compute();
         }
     }
@@ -373,8 +380,7 @@ WgPlan make_plan(const WgArgs& a, int k) {
     if (want < 1) want = 1;
     p.per_slab = (a.npatch + want - 1) / want;
     p.nslab = (int)((a.npatch + p.per_slab - 1) / p.per_slab);
-    // at most one workgroup per CU: nothing else hides the patch loads' latency -> four patches in flight (see k_wgrad2)
-    p.pf = (long)p.nslab * p.cot * p.cit <= 320 ? 4 : 1;
+    p.pf = 1;                                                 // see k_wgrad2: four patches in flight measured slower
     if (tu.pf == 1 || tu.pf == 4) p.pf = tu.pf;
     return p;
 }
