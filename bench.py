@@ -238,6 +238,54 @@ def measure_fsdp2(preset, batch, res, nc, dev, steps, warmup, precision="bfloat1
             dist.destroy_process_group()
 
 
+def measure_sharded(preset, batch, res, nc, dev, steps, warmup, precision="bfloat16"):
+    """BASELINE config 4 per GPU through `ShardedStepRunner` (src/training/sharded_step.py): the reference's FSDP2 numeric
+    contract (bf16 parameters and BatchNorm buffers, no autocast, fp32 master shards stepped by AdamW) with the step captured
+    as forward/backward/pack -> reduce-scatter -> shard update -> all-gather; on a one-rank RCCL group both collectives are
+    issued over one rank.  Bit-identical to the torch-FSDP2 step above in deterministic mode (tests/test_gpu_fsdp.py)."""
+    import socket
+    from src.model.losses import PackedTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.sharded_step import ShardedStepRunner
+    own = not dist.is_initialized()
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if own:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    try:
+        torch.manual_seed(0)
+        model = Model(**PRESETS[preset], num_classes=nc).to(dev).train()
+        runner = ShardedStepRunner(model, YoloDFLQFLoss(num_classes=nc), precision=precision, lr=1e-4, weight_decay=1e-4)
+        img, gts = synthetic_batch(batch, res, nc, 4321, dev)
+        runner.capture(img, PackedTargets(gts, dev))
+        for _ in range(warmup):
+            runner.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = runner.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dict(images_per_s=round(batch * steps / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), steps=steps, batch=batch,
+                    final_loss=round(float(loss), 5), runner="ShardedStepRunner", world=1, hip_graph=runner.graph is not None,
+                    collectives_per_step=["reduce_scatter_tensor AVG", "all_gather_into_tensor"],
+                    bytes_per_collective=int(runner.flat_g.numel() * runner.flat_g.element_size()), param_dtype=precision,
+                    master_shard_elems=int(runner.master.numel()))
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def config5_nms_tensor(bs=8, nc=80, m=33600, seed=0):
     """BASELINE config 5's NMS / IoU stress tensor: (bs, 4+nc, 33600), boxes random cxcywh on a 1280 canvas,
     ~15 % of the anchors confident (several thousand candidates per image after conf_thres 0.25, >= 300 kept)."""
@@ -445,6 +493,7 @@ def main():
             extra["nms_config5_fp16_8img"] = measure_nms(dev)
             extra["preset_s_640_bf16_32img_deterministic_mode"] = measure_preset("s", args.batch, args.res, nc, dev, steps=10, warmup=3, deterministic=True)
             extra["preset_l_fsdp2_bf16_16img"] = measure_fsdp2("l", 16, args.res, nc, dev, steps=10, warmup=3)
+            extra["preset_l_sharded_captured_bf16_16img"] = measure_sharded("l", 16, args.res, nc, dev, steps=20, warmup=5)
         except Exception as e:                     # never lose the headline line to an extra
             extra["error"] = repr(e)
 

@@ -33,6 +33,13 @@ def _loc(t):
     return t._local_tensor if isinstance(t, DTensor) else t
 
 
+def _grad(p):
+    """The gradient the kernel reads: `p.lowp_grad` when set (a bf16 / f16 gradient of an fp32 master parameter -- torch
+    refuses such a tensor as `.grad`; ShardedStepRunner's reduce-scattered shard), else `p.grad`."""
+    g = getattr(p, "lowp_grad", None)
+    return g if g is not None else p.grad
+
+
 class DeviceGradScaler:
     """torch.amp.GradScaler's state and rules (defaults: init_scale 65536, growth 2, backoff 0.5, interval 2000 -- what the
     reference constructs, src/training/train_model.py:195-208) held in device memory, for a training step that never
@@ -150,19 +157,19 @@ class HipAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
-            params = [p for p in group["params"] if p.grad is not None]
+            params = [p for p in group["params"] if _grad(p) is not None]
             if not params:
                 continue
             if group.get("amsgrad") or group.get("maximize"):
                 raise RuntimeError("HipAdamW implements plain AdamW (amsgrad=False, maximize=False)")
             plan = self._init_state(group, gi)
             capturing = torch.cuda.is_current_stream_capturing()
-            ptrs = tuple((_loc(p).data_ptr(), _loc(p.grad).data_ptr(), _loc(p).numel()) for p in params)
+            ptrs = tuple((_loc(p).data_ptr(), _loc(_grad(p)).data_ptr(), _loc(p).numel()) for p in params)
             if plan["ptrs"] != ptrs:
                 old = plan["ptrs"]
                 if (not capturing and old is not None and len(old) == len(ptrs) and plan["host"] is not None
                         and all(a[0] == b[0] and a[2] == b[2] for a, b in zip(old, ptrs))
-                        and plan.get("gdtypes") == tuple(p.grad.dtype for p in params)):
+                        and plan.get("gdtypes") == tuple(_grad(p).dtype for p in params)):
                     # same parameters, fresh gradient tensors (an eager loop's zero_grad(set_to_none=True)): one call
                     # rewrites the gradient pointers instead of a job_fill call per parameter
                     # The upload is asynchronous from one of TWO pinned staging tables; a table is rewritten only after
@@ -182,7 +189,7 @@ class HipAdamW(torch.optim.Optimizer):
                     evs[k].record()
                 else:
                     self._build(plan, params, capturing)
-                    plan["gdtypes"] = tuple(p.grad.dtype for p in params)
+                    plan["gdtypes"] = tuple(_grad(p).dtype for p in params)
                 plan["ptrs"] = ptrs
             if not capturing:
                 self.sync_hyper()
@@ -211,7 +218,7 @@ class HipAdamW(torch.optim.Optimizer):
         host = plan["host"]
         for i, p in enumerate(params):
             st = self.state[p]
-            w, g, m1, m2 = _loc(p), _loc(p.grad), _loc(st["exp_avg"]), _loc(st["exp_avg_sq"])
+            w, g, m1, m2 = _loc(p), _loc(_grad(p)), _loc(st["exp_avg"]), _loc(st["exp_avg_sq"])
             if not (w.is_contiguous() and g.is_contiguous() and m1.is_contiguous() and m2.is_contiguous()):
                 raise RuntimeError("HipAdamW needs contiguous parameters, gradients and moments")
             if not (g.numel() == m1.numel() == m2.numel() == w.numel()):

@@ -178,3 +178,63 @@ def test_fsdp2_step_uses_the_one_launch_optimizer_and_no_cast_kernels(pg):
     print(f"\n[fsdp2 bf16 step] {len(blocks)} Conv blocks ({n_dw} depthwise): {casts} dtype-conversion launches inside the blocks "
           f"in one forward + backward (round 2: eight per block)")
     assert casts <= 4 * n_dw, casts            # only the depthwise taps (fp32 [C][9] tables for the strip kernels) are converted
+
+
+def test_native_sharded_step_equals_the_torch_fsdp2_step_bitwise(pg, monkeypatch):
+    """`ShardedStepRunner` (config 4 as three captured pieces: forward/backward/pack, reduce-scatter, shard update, all-gather;
+    src/training/sharded_step.py) against torch's FSDP2 wrapper stepped by the reference's loop body, same model, batch and
+    hyper-parameters, three steps, deterministic mode (fixed-order BatchNorm statistics): the fp32 master weights, the
+    BatchNorm buffers and the loss scalars must be BIT-IDENTICAL -- same numeric contract (bf16 parameters and buffers, no
+    autocast), same kernels, only the schedule differs."""
+    from src.hipops import functions as F_
+    from src.model.losses import PackedTargets, YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training.sharded_step import ShardedStepRunner
+    from src.training.utils_train import get_optimizer, prepare_fsdp2_model
+    rank, world, gpu = pg
+    monkeypatch.setattr(F_, "DETERMINISTIC", True)
+    cfg = ob.PRESETS["n"]
+    g = torch.Generator().manual_seed(41)
+    img = torch.randn(2, 3, 160, 160, generator=g).cuda()
+    gts = [torch.cat([torch.rand(3, 2, generator=g) * 160, torch.rand(3, 2, generator=g) * 60 + 8,
+                      torch.randint(0, 80, (3, 1), generator=g).float()], 1).cuda() for _ in range(2)]
+    crit = YoloDFLQFLoss(num_classes=80)
+
+    def fresh():
+        m = Model(**cfg, num_classes=80)
+        det_fill_(m.state_dict(), 6)
+        return m
+
+    # A: torch FSDP2 over the HIP-backed model, the reference's loop body (src/training/train_model.py:234-253)
+    a = prepare_fsdp2_model(model=fresh(), device_id=gpu, config={"precision": "bfloat16"}, world_size=world, device="cuda").train()
+    opt, _ = get_optimizer(a, lr=1e-3, weight_decay=1e-2, patience=3, factor=0.5)
+    la = []
+    for _ in range(3):
+        opt.zero_grad()
+        preds, an, st = a(img)
+        loss, ld = crit(preds, gts, an, st)
+        loss.backward()
+        opt.step()
+        la.append(float(loss))
+    want = {_canon(k): p.full_tensor().detach().float().cpu() for k, p in a.named_parameters()}
+    want_buf = {_canon(k): b.detach().float().cpu() for k, b in a.named_buffers()}
+
+    # B: the native sharded step, captured
+    b = fresh().cuda().train()
+    runner = ShardedStepRunner(b, crit, precision="bfloat16", lr=1e-3, weight_decay=1e-2, use_graph=True)
+    runner.capture(img, PackedTargets(gts, img.device), warmup=1)          # the warm-up step is step 1
+    lb = [float(runner.warm_scalars[0])]
+    for _ in range(2):
+        lb.append(float(runner.step()))
+    torch.cuda.synchronize()
+    assert runner.graph is not None and runner.graph_c is not None
+    got = runner.full_state_dict()
+    assert la == lb, (la, lb)
+    bad = [k for k, v in want.items() if not torch.equal(got[k].float(), v)]
+    assert not bad, (len(bad), bad[:4], float((got[bad[0]].float() - want[bad[0]]).abs().max()))
+    bad = [k for k, v in want_buf.items() if not torch.equal(got[k].float(), v)]
+    assert not bad, bad[:4]
+    assert all(p.dtype == torch.bfloat16 for p in b.parameters()) and runner.master.dtype == torch.float32
+    # the gathered checkpoint loads into a bare fp32 Model
+    bare = Model(**cfg, num_classes=80)
+    bare.load_state_dict(got)
