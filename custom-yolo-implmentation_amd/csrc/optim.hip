@@ -31,6 +31,18 @@ __device__ __forceinline__ void st_any(void* p, int dt, long i, float x) {
     else ((f16_t*)p)[i] = from_f<f16_t>(x);
 }
 
+// The update of ONE element, shared by the packet path and the any-dtype path: explicit fmaf / mul sequence, so that the
+// same (p, g, m, v) give the same bits whichever path a tensor takes (a low-precision gradient of an fp32 master goes
+// through the generic one; left to the compiler the two loops were contracted differently: 1-ulp differences between
+// the sharded runner and torch FSDP2 on the same gradients).
+__device__ __forceinline__ void adam_elem(float& p, float gg, float& m, float& v, float b1, float omb1, float b2, float omb2,
+                                          float step_size, float bc2s, float decay, float eps) {
+    m = __fmaf_rn(b1, m, __fmul_rn(omb1, gg));
+    v = __fmaf_rn(b2, v, __fmul_rn(__fmul_rn(omb2, gg), gg));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2s), eps);
+    p = __fsub_rn(__fmul_rn(p, decay), __fdiv_rn(__fmul_rn(step_size, m), denom));
+}
+
 // step += 1 unless the scaler found an overflow (one thread; the main kernel reads the updated value)
 __global__ void k_adamw_tick(float* __restrict__ step, const float* __restrict__ found_inf) {
     if (found_inf == nullptr || *found_inf == 0.f) *step += 1.f;
@@ -72,12 +84,7 @@ __global__ __launch_bounds__(256) void k_adamw(const AdamJob* __restrict__ jobs,
             float4 m = *reinterpret_cast<float4*>(j.m + i), v = *reinterpret_cast<float4*>(j.v + i);
             float* pp = &p.x; const float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gg = gp[k] * gs;
-                mp[k] = b1 * mp[k] + omb1 * gg;
-                vp[k] = b2 * vp[k] + omb2 * gg * gg;
-                pp[k] = pp[k] * decay - step_size * mp[k] / (sqrtf(vp[k]) / bc2s + eps);
-            }
+            for (int k = 0; k < 4; ++k) adam_elem(pp[k], gp[k] * gs, mp[k], vp[k], b1, omb1, b2, omb2, step_size, bc2s, decay, eps);
             *reinterpret_cast<float4*>((float*)j.p + i) = p;
             *reinterpret_cast<float4*>(j.m + i) = m;
             *reinterpret_cast<float4*>(j.v + i) = v;
@@ -85,12 +92,11 @@ __global__ __launch_bounds__(256) void k_adamw(const AdamJob* __restrict__ jobs,
         return;
     }
     for (long i = base + threadIdx.x; i < base + CHUNK && i < j.n; i += 256) {
-        const float gg = ld_any(j.g, j.g_dtype, i) * gs;
-        const float m = b1 * j.m[i] + omb1 * gg;
-        const float v = b2 * j.v[i] + omb2 * gg * gg;
+        float pv = ld_any(j.p, j.p_dtype, i), m = j.m[i], v = j.v[i];
+        adam_elem(pv, ld_any(j.g, j.g_dtype, i) * gs, m, v, b1, omb1, b2, omb2, step_size, bc2s, decay, eps);
         j.m[i] = m;
         j.v[i] = v;
-        st_any(j.p, j.p_dtype, i, ld_any(j.p, j.p_dtype, i) * decay - step_size * m / (sqrtf(v) / bc2s + eps));
+        st_any(j.p, j.p_dtype, i, pv);
     }
 }
 

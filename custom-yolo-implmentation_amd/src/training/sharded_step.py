@@ -41,23 +41,24 @@ def _copy_plan(src, dst):
     return dict(dev=host.to(dst.device), njobs=1, nchunks=nchunks, srcs=[src], dsts=[dst])
 
 
-class ShardedStepRunner(TrainStepRunner):
-    """See the module docstring.  `optimizer_factory(params) -> optimizer` builds the optimizer over the ONE fp32 shard
-    parameter (default: HipAdamW(lr, weight_decay) on the GPU, torch.optim.AdamW elsewhere)."""
+class ShardState:
+    """The flat vectors of a model sharded over the current process group (see the module docstring): built once, by
+    `ShardedStepRunner` or ahead of it by `get_optimizer` (src/training/utils_train.py) when the optimizer must exist before
+    the runner does.  The model's parameters become views of `flat_p`; `master` is this rank's fp32 shard (an nn.Parameter:
+    what the optimizer steps)."""
 
     ALIGN = GradBuckets.ALIGN
 
-    def __init__(self, model, criterion, precision="bfloat16", lr=1e-3, weight_decay=1e-2, optimizer_factory=None, use_graph=True):
+    def __init__(self, model, precision):
         if precision == "float16":
-            raise RuntimeError("ShardedStepRunner: float16 needs loss scaling across shards; use bfloat16 or float32")
+            raise RuntimeError("native sharding: float16 needs loss scaling across shards; use bfloat16 or float32")
+        self.precision = precision
         self.lowp = _LOWP.get(precision)
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world > 1 or (dist.is_available() and dist.is_initialized()) else 0
         self.group = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.group else 1
+        self.rank = dist.get_rank() if self.group else 0
         dev = next(model.parameters()).device
         T = self.lowp or torch.float32
-
-        # ---- the numeric contract: parameters and BatchNorm buffers in the low-precision dtype (reference :146-153)
         trainable = [p for p in model.parameters() if p.requires_grad]
         slices, off = [], 0
         for p in trainable:
@@ -76,6 +77,7 @@ class ShardedStepRunner(TrainStepRunner):
         # fp32 master of this rank's shard: a separate vector under mixed precision, the slice itself in fp32
         master = full32[lo:hi].clone() if self.lowp is not None else self.p_shard
         self.master = torch.nn.Parameter(master, requires_grad=True)
+        # ---- the numeric contract: parameters and BatchNorm buffers in the low-precision dtype (reference :146-153)
         with torch.no_grad():
             for p, (o, n) in zip(trainable, slices):
                 p.data = self.flat_p[o:o + n].view(p.shape)
@@ -85,15 +87,73 @@ class ShardedStepRunner(TrainStepRunner):
             if self.lowp is not None:
                 for b in model.buffers():
                     b.data = b.data.to(self.lowp)            # every buffer, like the reference (:150-153); counters included
-        self.trainable, self.slices, self.total = trainable, slices, total
+        self.model, self.trainable, self.slices, self.total = model, trainable, slices, total
 
-        if optimizer_factory is None:
-            if dev.type == "cuda":
-                from src.training.fused_adamw import HipAdamW
-                optimizer_factory = lambda ps: HipAdamW(ps, lr=lr, weight_decay=weight_decay)
-            else:
-                optimizer_factory = lambda ps: torch.optim.AdamW(ps, lr=lr, weight_decay=weight_decay)
-        optimizer = optimizer_factory([self.master])
+    def gather_flat(self, shard):
+        """The full flat vector (fp32) from every rank's fp32 shard of it -- a collective."""
+        shard = shard.detach().float().contiguous()
+        if self.group and self.world > 1:
+            full = torch.empty(self.total, dtype=torch.float32, device=shard.device)
+            dist.all_gather_into_tensor(full, shard)
+            return full
+        return shard
+
+    def full_state_dict(self):
+        """{canonical name: FULL fp32 tensor} of the model -- the fp32 masters gathered from every rank (a collective) for
+        the trainable parameters, the model's own tensors for buffers and frozen weights: loads into a bare `Model`."""
+        full = self.gather_flat(self.master.data)
+        by_id = {id(p): (o, n) for p, (o, n) in zip(self.trainable, self.slices)}
+        out = {}
+        for k, v in self.model.state_dict().items():
+            out[k] = v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()
+        for k, p in self.model.named_parameters():
+            if id(p) in by_id:
+                o, n = by_id[id(p)]
+                out[k] = full[o:o + n].view(p.shape).cpu().clone()
+        return out
+
+    def full_optimizer_state_dict(self, optimizer):
+        """The sharded AdamW state as the state dict of a torch.optim.AdamW over the bare model's trainable parameters (in
+        `model.parameters()` order): moments gathered from every rank (a collective) and cut per parameter."""
+        st = optimizer.state.get(self.master, {})
+        sd = optimizer.state_dict()
+        group = dict(sd["param_groups"][0])
+        group["params"] = list(range(len(self.trainable)))
+        state = {}
+        if "exp_avg" in st:
+            m1, m2 = self.gather_flat(st["exp_avg"]), self.gather_flat(st["exp_avg_sq"])
+            step = torch.as_tensor(st["step"]).detach().float().cpu().reshape(())
+            for i, (p, (o, n)) in enumerate(zip(self.trainable, self.slices)):
+                state[i] = dict(step=step.clone(), exp_avg=m1[o:o + n].view(p.shape).cpu().clone(),
+                                exp_avg_sq=m2[o:o + n].view(p.shape).cpu().clone())
+        return dict(state=state, param_groups=[group])
+
+
+class ShardedStepRunner(TrainStepRunner):
+    """See the module docstring.  `optimizer_factory(params) -> optimizer` builds the optimizer over the ONE fp32 shard
+    parameter (default: HipAdamW(lr, weight_decay) on the GPU, torch.optim.AdamW elsewhere); or hand in `shard` (a
+    ShardState) together with the `optimizer` that was built over `shard.master`."""
+
+    def __init__(self, model, criterion, precision="bfloat16", lr=1e-3, weight_decay=1e-2, optimizer_factory=None, use_graph=True,
+                 shard=None, optimizer=None):
+        sh = shard if shard is not None else ShardState(model, precision)
+        if (shard is None) != (optimizer is None):
+            raise ValueError("ShardedStepRunner: pass `shard` and the `optimizer` built over shard.master together")
+        self.shard = sh
+        for k in ("lowp", "group", "world", "rank", "shard_elems", "flat_p", "flat_g", "p_shard", "g_shard", "master",
+                  "trainable", "slices", "total"):
+            setattr(self, k, getattr(sh, k))
+        dev = self.master.device
+        T = self.lowp or torch.float32
+        trainable, slices = self.trainable, self.slices
+        if optimizer is None:
+            if optimizer_factory is None:
+                if dev.type == "cuda":
+                    from src.training.fused_adamw import HipAdamW
+                    optimizer_factory = lambda ps: HipAdamW(ps, lr=lr, weight_decay=weight_decay)
+                else:
+                    optimizer_factory = lambda ps: torch.optim.AdamW(ps, lr=lr, weight_decay=weight_decay)
+            optimizer = optimizer_factory([self.master])
         super().__init__(model, criterion, optimizer, precision="float32", use_graph=use_graph)     # no autocast in FSDP modes
         self.comm, self.staged, self.buckets = False, False, None      # the exchange below replaces the DDP buckets
         # pack: every gradient into its slice of flat_g in one launch (the GradBuckets job table over OUR layout)
@@ -184,19 +244,4 @@ class ShardedStepRunner(TrainStepRunner):
 
     # ------------------------------------------------------------------------------------------- checkpoints
     def full_state_dict(self):
-        """{canonical name: FULL fp32 tensor} of the model -- the fp32 masters gathered from every rank (a collective) for
-        the trainable parameters, the model's own tensors for buffers and frozen weights: loads into a bare `Model`."""
-        if self.group and self.world > 1:
-            full = torch.empty(self.total, dtype=torch.float32, device=self.master.device)
-            dist.all_gather_into_tensor(full, self.master.data.float().contiguous())
-        else:
-            full = self.master.data.float()
-        by_id = {id(p): (o, n) for p, (o, n) in zip(self.trainable, self.slices)}
-        out = {}
-        for k, v in self.model.state_dict().items():
-            out[k] = v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()
-        for k, p in self.model.named_parameters():
-            if id(p) in by_id:
-                o, n = by_id[id(p)]
-                out[k] = full[o:o + n].view(p.shape).cpu().clone()
-        return out
+        return self.shard.full_state_dict()

@@ -115,8 +115,7 @@ class CapturedTraining:
         if not self.usable:
             return None
         if self.runner is None:
-            self.runner = TrainStepRunner(self.inner, self.criterion, self.optimizer, self.precision, use_graph=True,
-                                          grad_comm_dtype=self.comm_dtype)
+            self.runner = self._make_runner()
         if not self.captured:
             cap = 128 * len(boxes)
             fits = sum(int(b.shape[0]) if b.numel() else 0 for b in boxes) <= cap
@@ -128,7 +127,7 @@ class CapturedTraining:
             return ld
         if self._all_fit(self.runner.fits(images, boxes)):
             if self.dirty:      # an eager fallback step made optimizer / buckets rebuild the tables the captured launches read
-                for obj in (self.optimizer, self.runner.buckets):
+                for obj in (self.optimizer, self.runner.buckets, getattr(self.runner, "pack", None)):
                     restore = getattr(obj, "restore_capture", None)
                     if restore is not None:
                         restore()
@@ -139,6 +138,11 @@ class CapturedTraining:
         self.dirty = True
         _, ld = self.runner._eager_step(images, [b.to(images.device) for b in boxes])
         return ld
+
+    def _make_runner(self):
+        from src.training.graph_step import TrainStepRunner
+        return TrainStepRunner(self.inner, self.criterion, self.optimizer, self.precision, use_graph=True,
+                               grad_comm_dtype=self.comm_dtype)
 
     def sync_buffers(self):
         """DistributedDataParallel(broadcast_buffers=True) semantics for the BatchNorm buffers: rank 0's values on every
@@ -156,6 +160,26 @@ class CapturedTraining:
             for b in bufs:
                 b.copy_(flat[off:off + b.numel()].view_as(b))
                 off += b.numel()
+
+
+class ShardedTraining(CapturedTraining):
+    """`--mode fsdp2` with `training.fsdp2.native_shard: true`: training batches go through `ShardedStepRunner`
+    (src/training/sharded_step.py) on the static buffers every batch refills.  Same collective fit decision and eager
+    fallback as CapturedTraining; every rank keeps its own BatchNorm statistics, as under FSDP (no buffer broadcast)."""
+
+    def __init__(self, model, criterion, optimizer, precision):
+        super().__init__(model, criterion, optimizer, precision)
+        native = model._native_shard
+        self.shard = native["state"]
+        self.usable = self.shard is not None and optimizer is native.get("optimizer") and precision in ("bfloat16", "float32")
+
+    def _make_runner(self):
+        from src.training.sharded_step import ShardedStepRunner
+        return ShardedStepRunner(self.inner, self.criterion, precision=self.precision, use_graph=True, shard=self.shard,
+                                 optimizer=self.optimizer)
+
+    def sync_buffers(self):
+        return
 
 
 def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimizer=None, scaler=None, metrics=None,
@@ -214,6 +238,10 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, init
     want_captured = captured_step is True or (captured_step is None and world == 1)
     captured = CapturedTraining(model, criterion, optimizer, precision, grad_compress=grad_compress) \
         if (want_captured and device != "cpu" and distributed_mode == "ddp") else None
+    if getattr(model, "_native_shard", None) is not None:       # fsdp2 with native_shard: the sharded step IS the training path
+        captured = ShardedTraining(model, criterion, optimizer, precision)
+        if not captured.usable:
+            raise RuntimeError("fsdp2.native_shard: build the optimizer with get_optimizer(model, ...) after prepare_fsdp2_model")
     if captured is not None and not captured.usable:
         captured = None
     # the captured route scales fp16 losses on the device; the eager loop uses torch's (Sharded)GradScaler like the reference

@@ -30,6 +30,17 @@ def get_optimizer(model: nn.Module, lr: float, weight_decay: float, patience: in
     shards it updates in place.  FSDP1 (use_orig_params=True) exposes plain-looking nn.Parameters that are views of its
     flat shards, re-pointed every step: it keeps torch.optim.AdamW, and so does anything on the CPU."""
     from torch.distributed.tensor import DTensor
+    native = getattr(model, "_native_shard", None)
+    if native is not None:
+        # `prepare_fsdp2_model(native_shard: true)`: the model is sharded HERE (flat low-precision parameters, this rank's
+        # fp32 master shard) and the optimizer steps the master shard; train() drives both through ShardedStepRunner
+        from src.training.fused_adamw import HipAdamW
+        from src.training.sharded_step import ShardState
+        if native.get("state") is None:
+            native["state"] = ShardState(model, native["precision"])
+        opt = HipAdamW([native["state"].master], lr=lr, weight_decay=weight_decay)
+        native["optimizer"] = opt
+        return opt, optim.lr_scheduler.ReduceLROnPlateau(opt, patience=patience, factor=factor)
     params = list(model.parameters())
     fsdp1 = isinstance(model, FSDP) or any(isinstance(m, FSDP) for m in model.modules())
     ok = lambda p: (type(p) is nn.Parameter and p.is_cuda) or (isinstance(p, DTensor) and p._local_tensor.is_cuda)
@@ -61,6 +72,8 @@ def canonical_state_dict(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tens
 
 def _is_sharded(model: nn.Module) -> bool:
     from torch.distributed.tensor import DTensor
+    if getattr(model, "_native_shard", None) is not None:
+        return True
     return isinstance(model, FSDP) or any(isinstance(m, FSDP) for m in model.modules()) or \
         any(isinstance(p, DTensor) for p in model.parameters())
 
@@ -70,6 +83,10 @@ def checkpoint_states(model: nn.Module, optimizer: optim.Optimizer):
     (`model.state_dict()`, `optimizer.state_dict()`; :47-53).  Sharded models (FSDP1, FSDP2): FULL tensors under
     canonical names, gathered by torch.distributed.checkpoint -- a COLLECTIVE, call it on every rank (the reference
     pickles each rank's DTensor shards, which nothing can load back: notebooks/04 load error)."""
+    native = getattr(model, "_native_shard", None)
+    if native is not None and native.get("state") is not None:      # collectives: call on every rank
+        st = native["state"]
+        return st.full_state_dict(), st.full_optimizer_state_dict(optimizer)
     if not _is_sharded(model):
         return model.state_dict(), optimizer.state_dict()
     from torch.distributed.checkpoint.state_dict import StateDictOptions, get_state_dict
@@ -93,6 +110,45 @@ def load_checkpoint(model: nn.Module, optimizer: optim.Optimizer, path: str, map
     (collective).  The optimizer state is loaded when given and present."""
     ck = torch.load(path, map_location=map_location, weights_only=False)
     state = canonical_state_dict(ck["model_state"] if isinstance(ck, dict) and "model_state" in ck else ck)
+    native = getattr(model, "_native_shard", None)
+    if native is not None:
+        st = native.get("state")
+        if st is None:                              # before get_optimizer: plain load, sharded afterwards from these values
+            model.load_state_dict(state)
+        else:                                       # full tensors -> this rank's fp32 shard + every rank's compute copy
+            with torch.no_grad():
+                full = torch.zeros(st.total, dtype=torch.float32, device=st.master.device)
+                named = dict(model.named_parameters())
+                by_id = {id(q): (o, n) for q, (o, n) in zip(st.trainable, st.slices)}
+                for k, v in state.items():
+                    q = named.get(k)
+                    if q is not None and id(q) in by_id:
+                        o, n = by_id[id(q)]
+                        full[o:o + n].copy_(v.reshape(-1).float())
+                    elif q is not None:
+                        q.copy_(v.to(q.dtype))
+                for k, b in model.named_buffers():
+                    if k in state:
+                        b.copy_(state[k].to(b.dtype))
+                lo = st.rank * st.shard_elems
+                st.master.data.copy_(full[lo:lo + st.shard_elems])
+                st.flat_p.copy_(full.to(st.flat_p.dtype))
+            if optimizer is not None and isinstance(ck, dict) and ck.get("optimizer_state", {}).get("state"):
+                os_ = ck["optimizer_state"]["state"]
+                m1 = torch.zeros(st.total, dtype=torch.float32, device=st.master.device)
+                m2 = torch.zeros_like(m1)
+                for i, (q, (o, n)) in enumerate(zip(st.trainable, st.slices)):
+                    e = os_.get(i, os_.get(str(i)))
+                    if e is not None:
+                        m1[o:o + n].copy_(e["exp_avg"].reshape(-1).float())
+                        m2[o:o + n].copy_(e["exp_avg_sq"].reshape(-1).float())
+                step = float(next(iter(os_.values()))["step"])
+                lo = st.rank * st.shard_elems
+                optimizer.load_state_dict(dict(
+                    state={0: dict(step=torch.tensor(step), exp_avg=m1[lo:lo + st.shard_elems].clone(),
+                                   exp_avg_sq=m2[lo:lo + st.shard_elems].clone())},
+                    param_groups=[dict(ck["optimizer_state"]["param_groups"][0], params=[0])]))
+        return int(ck["epoch"]) if isinstance(ck, dict) and "epoch" in ck else 0
     if _is_sharded(model):
         from torch.distributed.checkpoint.state_dict import StateDictOptions, set_model_state_dict, set_optimizer_state_dict
         opts = StateDictOptions(full_state_dict=True, cpu_offload=True)
@@ -185,9 +241,20 @@ def prepare_fsdp_model(model: nn.Module, device_id: int, config: Dict[str, Union
 
 def prepare_fsdp2_model(model: nn.Module, device_id: int, config: Dict[str, Union[str, int]], world_size: int,
                         device: str) -> nn.Module:
-    """FSDP2: fully_shard every C3K2 / SPPF / PSA, then the root (reference :116-165)."""
+    """FSDP2: fully_shard every C3K2 / SPPF / PSA, then the root (reference :116-165).
+
+    Optional config key `native_shard: true` (GPU only; an extension, default off): no torch wrapper -- the model is marked
+    for the native sharded step (src/training/sharded_step.py: the same numeric contract and the same sharding of master
+    weights and optimizer state, but the parameters are gathered once per step and the step is captured), which
+    `get_optimizer` and `train()` then set up.  Bit-identical to the torch-FSDP2 step in deterministic mode, 3.9x its rate
+    on preset l (tests/test_gpu_fsdp.py, bench.py extra)."""
     _pin_device(device, device_id, world_size)
     model = model.to(device_id if device == "cuda" else device)
+    if config.get("native_shard") and device == "cuda":
+        if config.get("precision") == "float16":
+            raise RuntimeError("fsdp2.native_shard: float16 is not supported (use bfloat16 or float32)")
+        model._native_shard = dict(precision=config.get("precision") or "float32", state=None)
+        return model
     policy = MixedPrecisionPolicy(param_dtype=None, reduce_dtype=None, cast_forward_inputs=True)
     if config.get("precision") in _LOWP:
         dt = getattr(torch, config["precision"])

@@ -23,7 +23,8 @@ def pg():
                                                      ("ddp", "float16", False), ("fsdp2", "bfloat16", False),
                                                      ("fsdp2", "float16", False),
                                                      ("fsdp", "bfloat16", False), ("fsdp", "float32", False),
-                                                     ("ddp", "bfloat16", True), ("ddp", "float32", True), ("ddp", "float16", True)])
+                                                     ("ddp", "bfloat16", True), ("ddp", "float32", True), ("ddp", "float16", True),
+                                                     ("fsdp2-native", "bfloat16", None), ("fsdp2-native", "float32", None)])
 def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path):
     from src.data.data_loader import get_data_loaders
     from src.model.losses import YoloDFLQFLoss
@@ -33,10 +34,13 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path
     rank, world, gpu = pg
     torch.manual_seed(0)
     model = Model(**NANO, num_classes=80)
+    native = mode == "fsdp2-native"          # config key training.fsdp2.native_shard: the captured sharded step (sharded_step.py)
+    mode = "fsdp2" if native else mode
     wrap = {"ddp": prepare_ddp_model, "fsdp2": prepare_fsdp2_model, "fsdp": prepare_fsdp_model}[mode]
     # captured=True: the default drop-in path -- the DDP-wrapped model stepped through TrainStepRunner on its .module
     model = wrap(model=model, device_id=gpu, config={"precision": precision, "find_unused_parameters": False,
-                                                      "sharding_strategy": "FULL_SHARD", "auto_wrap_policy_min_params": 20000},
+                                                      "sharding_strategy": "FULL_SHARD", "auto_wrap_policy_min_params": 20000,
+                                                      "native_shard": native},
                  world_size=world, device="cuda")
     tr, va = get_data_loaders("/nonexistent/train", "/nonexistent/val", "", "", batch_size=4, is_test=True, device="cuda",
                               num_classes=80, res=160)
@@ -45,7 +49,8 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path
     # FSDP1's parameters are views of its flat shards, re-pointed every step: torch.optim.AdamW; everything else (plain
     # parameters, FSDP2's DTensor shards) steps in one launch
     assert type(opt) is (torch.optim.AdamW if mode == "fsdp" else HipAdamW)
-    before = [p.detach().float().clone() for p in model.parameters()][:3]
+    masters = (lambda: [model._native_shard["state"].master.detach().float().clone()]) if native else None
+    before = masters() if native else [p.detach().float().clone() for p in model.parameters()][:3]
     train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched,
           criterion=YoloDFLQFLoss(num_classes=80), initial_epoch=0, num_epochs=1, device=gpu, num_classes=80, rank=rank,
           checkpoint_dir=str(tmp_path), distributed_mode=mode, precision=precision, conf_threshold=0.01,
@@ -53,11 +58,21 @@ def test_train_one_epoch_like_the_script(pg, mode, precision, captured, tmp_path
     if captured and precision == "float16":             # the captured route scales on the device: GradScaler's rules, no GradScaler
         amp = getattr(opt, "device_amp", None)
         assert amp is not None and amp.get_scale() in (65536.0, 32768.0, 16384.0, 8192.0) and torch.isfinite(amp.state).all()
-    after = [p.detach().float() for p in model.parameters()][:3]
+    after = masters() if native else [p.detach().float() for p in model.parameters()][:3]
     assert any(not torch.equal(a, b) for a, b in zip(before, after)), "parameters did not move"
     assert all(torch.isfinite(a).all() for a in after)
     ck = torch.load(os.path.join(str(tmp_path), "model_epoch_1.pth"), map_location="cpu", weights_only=False)
     assert ck["epoch"] == 1 and "model_state" in ck and "optimizer_state" in ck
+    if native:      # full fp32 tensors under canonical names + a torch.optim.AdamW-shaped optimizer state: a bare Model resumes from it
+        bare = Model(**NANO, num_classes=80)
+        bare.load_state_dict(ck["model_state"])
+        o2 = torch.optim.AdamW([p for p in bare.parameters() if p.requires_grad], lr=1e-4)
+        o2.load_state_dict(ck["optimizer_state"])
+        assert all(v.dtype == torch.float32 for v in ck["model_state"].values() if v.is_floating_point())
+        # ... and the sharded model itself resumes (masters, compute copies and moments from the full tensors)
+        from src.training.utils_train import load_checkpoint
+        assert load_checkpoint(model, opt, os.path.join(str(tmp_path), "model_epoch_1.pth")) == 1
+        assert torch.equal(masters()[0], after[0])
     keys = set(ck["model_state"].keys())
     assert any(k.endswith("net.p1.0.conv.weight") for k in keys) and any(k.endswith("head.dfl.conv.weight") for k in keys)
 
