@@ -1,6 +1,7 @@
 // HBM-bound NHWC kernels: layout changes, channel copies, BatchNorm (+SiLU, +residual) forward and
 // backward, SPPF max-pool, nearest x2 upsample.  One 16-byte packet per lane wherever the channel
 // count allows it (guide: Guideline 13), fp32 arithmetic, fp32 statistics.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -343,7 +344,10 @@ template <typename T, int V, int MODE, int ACT>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_channel_acc(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                              long npix, int C, int act, float* __restrict__ acc, int tpr) {
+                              long npix, int C, int act, float* __restrict__ acc, int tpr, int rev) {
+    const long pix_b = rev ? npix - 1 : 0, pix_d = rev ? -1 : 1;   // traversal direction (see bn_rev())
+#define PIX(p_) (pix_b + pix_d * (p_))
+
     __shared__ float red[TPB][2 * V + 1];
     const int cv = C / V;
     const int rpb = TPB / tpr;
@@ -379,15 +383,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             pack_t<T, V> ra[RS_ROWS], rd[RS_ROWS];
 #pragma unroll
             for (int k = 0; k < RS_ROWS; ++k) {
-                ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
-                if (MODE == 1) rd[k] = load_raw<T, V>(dout + (p + k * step) * ldd + cg * V);
+                ra[k] = load_raw<T, V>(y + PIX(p + k * step) * ldy + cg * V);
+                if (MODE == 1) rd[k] = load_raw<T, V>(dout + PIX(p + k * step) * ldd + cg * V);
             }
 #pragma unroll
             for (int k = 0; k < RS_ROWS; ++k) one(ra[k], rd[k]);
         }
         for (; p < npix; p += step) {
-            pack_t<T, V> pa = load_raw<T, V>(y + p * ldy + cg * V), pd;
-            if (MODE == 1) pd = load_raw<T, V>(dout + p * ldd + cg * V);
+            pack_t<T, V> pa = load_raw<T, V>(y + PIX(p) * ldy + cg * V), pd;
+            if (MODE == 1) pd = load_raw<T, V>(dout + PIX(p) * ldd + cg * V);
             one(pa, pd);
         }
     }
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (cgo < cv) atomicAdd(o + (j / V) * C + cgo * V + (j % V), a);
     }
 }
+#undef PIX
 
 // acc[8][2][C] -> mean, invstd, scale, shift (+ running statistics): one thread per channel, 16 loads
 __global__ void k_bn_finalize_acc(const float* __restrict__ acc, float count, int C, const void* __restrict__ gamma_,
@@ -441,7 +446,10 @@ __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ 
                         const void* __restrict__ gamma_, const void* __restrict__ beta_, void* __restrict__ rmean_,
                         void* __restrict__ rvar_, float momentum, float eps, float* __restrict__ mean_out,
                         float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
-                        const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C, int act, int tpr, int pdt, int bdt) {
+                        const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo, long npix, int C, int act, int tpr, int pdt, int bdt, int rev) {
+    const long pix_b = rev ? npix - 1 : 0, pix_d = rev ? -1 : 1;   // traversal direction (see bn_rev())
+#define PIX(p_) (pix_b + pix_d * (p_))
+
     const PIn gamma{gamma_, pdt}; const PIn beta{beta_, pdt}; const PIo rmean{rmean_, bdt}, rvar{rvar_, bdt};
     extern __shared__ float cf[];                            // [2][cw]: scale, shift of this workgroup's channels
     const int cv = C / V;
@@ -490,25 +498,26 @@ __global__ __launch_bounds__(TPB) void k_bn_act_fwd_train(const T* __restrict__ 
         if (res) unpack<T, V>(pt, t);
 #pragma unroll
         for (int j = 0; j < V; ++j) a[j] = act_fwd(a[j] * sc[j] + sh[j], ACT) + (res ? t[j] : 0.f);
-        store_pack<T, V>(out + p * ldo + cg * V, a);
+        store_pack<T, V>(out + PIX(p) * ldo + cg * V, a);
     };
     long p = (long)blockIdx.x * rpb + r;
     for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {
         pack_t<T, V> ra[RS_ROWS], rt[RS_ROWS];
 #pragma unroll
         for (int k = 0; k < RS_ROWS; ++k) {
-            ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
-            if (res) rt[k] = load_raw<T, V>(res + (p + k * step) * ldr + cg * V);
+            ra[k] = load_raw<T, V>(y + PIX(p + k * step) * ldy + cg * V);
+            if (res) rt[k] = load_raw<T, V>(res + PIX(p + k * step) * ldr + cg * V);
         }
 #pragma unroll
         for (int k = 0; k < RS_ROWS; ++k) one(p + k * step, ra[k], rt[k]);
     }
     for (; p < npix; p += step) {
-        pack_t<T, V> pa = load_raw<T, V>(y + p * ldy + cg * V), pt;
-        if (res) pt = load_raw<T, V>(res + p * ldr + cg * V);
+        pack_t<T, V> pa = load_raw<T, V>(y + PIX(p) * ldy + cg * V), pt;
+        if (res) pt = load_raw<T, V>(res + PIX(p) * ldr + cg * V);
         one(p, pa, pt);
     }
 }
+#undef PIX
 
 // dy = A*dz + B*y + D with the backward finalize folded in: acc[8][2][C] holds (sum dz, sum dz*y) of the reduction
 // kernel (float atomics into 8 replicas); every workgroup folds the replicas of ITS channels, centres the second
@@ -521,7 +530,10 @@ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __re
                               const void* __restrict__ gamma_, const float* __restrict__ mean,
                               const float* __restrict__ invstd, const float* __restrict__ acc, float count,
                               void* __restrict__ dgamma_, void* __restrict__ dbeta_, T* __restrict__ dy, int lddy,
-                              long npix, int C, int act, int tpr, int pdt) {
+                              long npix, int C, int act, int tpr, int pdt, int rev) {
+    const long pix_b = rev ? npix - 1 : 0, pix_d = rev ? -1 : 1;   // traversal direction (see bn_rev())
+#define PIX(p_) (pix_b + pix_d * (p_))
+
     const PIn gamma{gamma_, pdt}; const PIo dgamma{dgamma_, pdt}, dbeta{dbeta_, pdt};
     extern __shared__ float cf[];                            // [5][cw]: scale, shift, A, B, D
     const int cv = C / V;
@@ -559,22 +571,23 @@ void k_bn_act_bwd_apply_train(const T* __restrict__ dout, int ldd, const T* __re
 #pragma unroll
         for (int j = 0; j < V; ++j)
             d[j] = my[2 * cw + j] * (d[j] * act_grad(a[j] * my[j] + my[cw + j], ACT)) + my[3 * cw + j] * a[j] + my[4 * cw + j];
-        store_pack<T, V>(dy + p * lddy + cg * V, d);
+        store_pack<T, V>(dy + PIX(p) * lddy + cg * V, d);
     };
     long p = (long)blockIdx.x * rpb + r;
     for (; p + (RS_ROWS - 1) * step < npix; p += RS_ROWS * step) {
         pack_t<T, V> ra[RS_ROWS], rd[RS_ROWS];
 #pragma unroll
         for (int k = 0; k < RS_ROWS; ++k) {
-            ra[k] = load_raw<T, V>(y + (p + k * step) * ldy + cg * V);
-            rd[k] = load_raw<T, V>(dout + (p + k * step) * ldd + cg * V);
+            ra[k] = load_raw<T, V>(y + PIX(p + k * step) * ldy + cg * V);
+            rd[k] = load_raw<T, V>(dout + PIX(p + k * step) * ldd + cg * V);
         }
 #pragma unroll
         for (int k = 0; k < RS_ROWS; ++k) one(p + k * step, ra[k], rd[k]);
     }
     for (; p < npix; p += step)
-        one(p, load_raw<T, V>(y + p * ldy + cg * V), load_raw<T, V>(dout + p * ldd + cg * V));
+        one(p, load_raw<T, V>(y + PIX(p) * ldy + cg * V), load_raw<T, V>(dout + PIX(p) * ldd + cg * V));
 }
+#undef PIX
 
 // Finalize kernels run as (32 channels x 32 parts) 1024-thread workgroups: part j sums partial blocks
 // j, j+32, ... of its channel (128-byte coalesced rows), LDS combines the 32 parts; the thread with
@@ -937,6 +950,14 @@ inline dim3 rs_grid(long npix, int cv) {
 // 16-lane rows (256-byte segments, channel groups on blockIdx.y): measured 12.1 -> 10.2 us forward and 30.6 -> 24.6 us
 // backward for 512 channels at 20x20 x 32 images; capping the workgroup count as well made the 64..128-channel
 // layers slower and is not done.
+// Traversal direction of the three training-mode BatchNorm passes, one bit each (1 = from the last pixel down): bit 0 the
+// forward normalise pass, bit 1 the backward reduction, bit 2 the backward apply.  A pass that walks a tensor in the
+// direction OPPOSITE to the pass that last touched it meets that pass's most recent lines first -- still in the L2s / the
+// 256 MB Infinity Cache -- instead of evicting them on its way to them.  YOLO_BN_REV overrides (A/B runs).
+static inline int bn_rev() {
+    static const int v = [] { const char* e = getenv("YOLO_BN_REV"); return e ? atoi(e) : 0; }();
+    return v;
+}
 struct RsPlan { int tpr; dim3 grid; };
 inline RsPlan rs_plan(long npix, int cv) {
     RsPlan p;
@@ -1211,13 +1232,13 @@ static int launch_acc(int mode, const void* y, int ldy, const void* dout, int ld
             const RsPlan pl = rs_plan(npix, C / V);
             if (mode == 0)
                 hipLaunchKernelGGL((k_channel_acc<T, V, 0, 0>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)nullptr, 0,
-                                   gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr);
+                                   gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr, (bn_rev() >> (mode ? 1 : 0)) & 1);
             else if (act)     // the activation is a template parameter: no per-element select between SiLU and identity
                 hipLaunchKernelGGL((k_channel_acc<T, V, 1, 1>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)dout, ldd,
-                                   gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr);
+                                   gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr, (bn_rev() >> (mode ? 1 : 0)) & 1);
             else
                 hipLaunchKernelGGL((k_channel_acc<T, V, 1, 0>), pl.grid, dim3(TPB), 0, st, (const T*)y, ldy, (const T*)dout, ldd,
-                                   gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr);
+                                   gamma, beta, mean, invstd, npix, C, act, acc, pl.tpr, (bn_rev() >> (mode ? 1 : 0)) & 1);
         });
     });
     return YOLO_LAUNCH_CHECK();
@@ -1248,11 +1269,11 @@ int yolo_bn_act_fwd_train(const void* y, int ldy, const float* acc, long count, 
             if (act)
                 hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 1>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
                                (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
-                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr, pdtype, bdtype);
+                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr, pdtype, bdtype, bn_rev() & 1);
             else
                 hipLaunchKernelGGL((k_bn_act_fwd_train<T, V, 0>), pl.grid, dim3(TPB), 2 * pl.tpr * V * sizeof(float), st,
                                (const T*)y, ldy, acc, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
-                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr, pdtype, bdtype);
+                               mean, invstd, scale, shift, (const T*)res, ldres, (T*)out, ldout, npix, C, act, pl.tpr, pdtype, bdtype, bn_rev() & 1);
         });
     });
     return YOLO_LAUNCH_CHECK();
@@ -1276,11 +1297,11 @@ int yolo_bn_act_bwd_apply_train(const void* dout, int ldd, const void* y, int ld
             if (act)
                 hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 1>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
                                (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
-                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr, pdtype);
+                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr, pdtype, (bn_rev() >> 2) & 1);
             else
                 hipLaunchKernelGGL((k_bn_act_bwd_apply_train<T, V, 0>), pl.grid, dim3(TPB), 5 * pl.tpr * V * sizeof(float), st,
                                (const T*)dout, ldd, (const T*)y, ldy, scale, shift, gamma, mean, invstd, acc, (float)count,
-                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr, pdtype);
+                               dgamma, dbeta, (T*)dy, lddy, npix, C, act, pl.tpr, pdtype, (bn_rev() >> 2) & 1);
         });
     });
     return YOLO_LAUNCH_CHECK();

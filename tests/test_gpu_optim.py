@@ -166,7 +166,10 @@ def test_loss_kernel_applies_the_scale_in_fp32_before_rounding():
     out3, d3, _ = ops.loss_fwd_bwd(preds.float(), anchors.float(), strides.float(), *pk.as_tuple(), nc, 1.5, 1.0, True)
     assert torch.equal(out1, out2)                                  # the loss VALUE is never scaled
     want = d3 * 65536.0
-    err_in = float((d2.float() - want).abs().max() / want.abs().max())
-    err_post = float((d1.float() * 65536.0 - want).abs().max() / want.abs().max())
-    print(f"\n[fp16 loss scaling] max error vs fp32 gradient: in-kernel {err_in:.2e}, scaled after rounding {err_post:.2e}")
-    assert err_in < 1e-3 and torch.isfinite(d2.float()).all() and err_post > 2 * err_in
+    small = (d3.abs() < 6e-5) & (d3.abs() > 2e-7)                   # unscaled values in fp16's subnormal range
+    assert int(small.sum()) > 1000
+    rel_in = float(((d2.float() - want).abs() / want.abs())[small].mean())
+    rel_post = float(((d1.float() * 65536.0 - want).abs() / want.abs())[small].mean())
+    print(f"\n[fp16 loss scaling] mean relative error of the {int(small.sum())} gradients that are subnormal before scaling: "
+          f"scaled in the kernel (fp32) {rel_in:.2e}, scaled after the fp16 rounding {rel_post:.2e}")
+    assert rel_in < 1e-3 and torch.isfinite(d2.float()).all() and rel_post > 4 * rel_in
