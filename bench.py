@@ -301,6 +301,42 @@ def config5_nms_tensor(bs=8, nc=80, m=33600, seed=0):
     return pred
 
 
+def measure_inference(dev, preset="l", res=1280, batch=4, nc=80, reps=10):
+    """BASELINE config 5's model half: `Model.fuse()` + forward + decode + class-aware NMS of preset l at 1280 x 1280 in fp16
+    (random weights; the class logits are shifted so that thousands of candidates pass the confidence threshold): ms / image."""
+    from src.hipops import ops
+    from src.model.model_builder import Model
+    from src.utils.model_utils import non_max_suppression
+    torch.manual_seed(0)
+    model = Model(**PRESETS[preset], num_classes=nc).to(dev).eval().fuse()
+    img = torch.randn(batch, 3, res, res, device=dev)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            preds, anchors, strides = model(img)
+            preds[:, 64:] += 5.0
+            y = ops.head_decode(preds, anchors, strides, nc)
+            return non_max_suppression(y, conf_thres=0.25, iou_thres=0.45, nc=nc)
+    out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = run()
+    torch.cuda.synchronize()
+    full = (time.perf_counter() - t0) / reps * 1e3
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        model(img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model(img)
+        torch.cuda.synchronize()
+    fwd = (time.perf_counter() - t0) / reps * 1e3
+    return dict(ms_per_image=round(full / batch, 3), forward_ms_per_image=round(fwd / batch, 3), images_per_s=round(1e3 * batch / full, 1),
+                batch=batch, anchors=int(sum((res // s) ** 2 for s in (8, 16, 32))), kept_per_image=sum(o.shape[0] for o in out) // batch,
+                eager_launches=True)
+
+
 def measure_nms(dev):
     """Class-aware NMS on BASELINE config 5's tensor (8 x 84 x 33600, fp16) on the device: ms per image."""
     from src.utils.model_utils import non_max_suppression
@@ -491,6 +527,7 @@ def main():
         try:
             extra["preset_l_640_bf16_16img"] = measure_preset("l", 16, args.res, nc, dev, steps=20, warmup=5)
             extra["nms_config5_fp16_8img"] = measure_nms(dev)
+            extra["inference_l_1280_fp16_fused"] = measure_inference(dev)
             extra["preset_s_640_bf16_32img_deterministic_mode"] = measure_preset("s", args.batch, args.res, nc, dev, steps=10, warmup=3, deterministic=True)
             extra["preset_l_fsdp2_bf16_16img"] = measure_fsdp2("l", 16, args.res, nc, dev, steps=10, warmup=3)
             extra["preset_l_sharded_captured_bf16_16img"] = measure_sharded("l", 16, args.res, nc, dev, steps=20, warmup=5)

@@ -38,6 +38,9 @@ struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic i
     float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
     const void* acc2;            // ACC launches: second accumulate source (row stride ld2) or null
     int ld2;
+    int act;                     // inference epilogue: 1 = SiLU after the bias
+    const void* res;             // inference epilogue: residual added after the activation (row stride ldr) or null
+    int ldr;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -68,6 +71,21 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 
 
+// the inference epilogue on one group of four channels: v = act(v) (+ residual)
+template <typename T>
+__device__ __forceinline__ void fused_epilogue(float (&v)[4], int act, const void* res, long off) {
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * __frcp_rn(1.f + __expf(-v[r]));
+    }
+    if (res != nullptr) {
+        float o[4];
+        load_pack<T, 4>((const T*)res + off, o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += o[r];
+    }
+}
+
 inline GeomDev to_dev(const ConvGeom& g) {
     GeomDev d;
     d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd;
@@ -76,6 +94,7 @@ inline GeomDev to_dev(const ConvGeom& g) {
     d.dh_pack = d.dw_pack = 0;
     d.stats = g.stats;
     d.acc2 = g.acc2; d.ld2 = g.ld2;
+    d.act = g.act; d.res = g.res; d.ldr = g.ldr;
     d.tap_inner = 0;
     d.dma = 1;      // LDS-DMA staging: level or a few % ahead of register staging on every shape of tools/conv_tune.py
     for (int t = 0; t < g.ntaps; ++t) {

@@ -334,6 +334,7 @@ ConvGeom fwd_geom(int ldx, int ldy, float* stats_acc, int N, int H, int W, int C
     ConvGeom g;
     g.stats = stats_acc;
     g.acc2 = nullptr; g.ld2 = 0;
+    g.act = 0; g.res = nullptr; g.ldr = 0;
     g.N = N; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lds = ldx;
     g.Hd = OH; g.Wd = OW; g.Cd = Cout; g.ldd = ldy; g.Hg = OH; g.Wg = OW;
     g.ostep = 1; g.ooff_h = 0; g.ooff_w = 0; g.sstride = stride;
@@ -348,6 +349,7 @@ ConvGeom dgrad_geom(int lddy, int lddx, int N, int H, int W, int Cin, int OH, in
     ConvGeom g;
     g.stats = nullptr;
     g.acc2 = nullptr; g.ld2 = 0;
+    g.act = 0; g.res = nullptr; g.ldr = 0;
     g.N = N; g.Hs = OH; g.Ws = OW; g.Cs = Cout; g.lds = lddy;
     g.Hd = H; g.Wd = W; g.Cd = Cin; g.ldd = lddx;
     int kh[9], kw[9];
@@ -437,6 +439,23 @@ int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, v
     if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return YOLO_ERR_ARG;
     ConvGeom g = fwd_geom(ldx, ldy, stats_acc, N, H, W, Cin, OH, OW, Cout, k, stride);
     return run_conv(g, x, wp, bias, y, 0, dtype, algo, st);
+}
+
+// Inference form of a fused Conv block (Model.fuse(): BatchNorm folded into the weights and a bias, reference
+// src/model/model_blocks.py:36-37, src/utils/model_utils.py:72-118): y = act(conv(x) + bias) (+ res) in ONE launch -- bias,
+// SiLU and the residual add of Residual / PSABlock ride in the epilogue of the MFMA kernels.  Returns 1 (nothing launched)
+// when the shape / dtype has no MFMA kernel (fp32, unaligned channels): the caller then runs conv + the element-wise pass.
+int yolo_conv2d_fwd_act(const void* x, int ldx, const void* wp, const float* bias, const void* res, int ldr, void* y, int ldy,
+                        int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int act, int dtype,
+                        hipStream_t st) {
+    if (!supported(k, stride) || (act != 0 && act != 1)) return YOLO_ERR_ARG;
+    int pad = k / 2;
+    if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return YOLO_ERR_ARG;
+    if (res != nullptr && ((ldr & 3) || (reinterpret_cast<uintptr_t>(res) & 7))) return 1;
+    ConvGeom g = fwd_geom(ldx, ldy, nullptr, N, H, W, Cin, OH, OW, Cout, k, stride);
+    g.act = act; g.res = res; g.ldr = ldr;
+    if (!mfma_conv_eligible(g, dtype, x, wp, y)) return 1;
+    return mfma_conv_launch(g, x, wp, bias, y, 0, dtype, st);
 }
 
 // dx[N,H,W,Cin] (= or +=) conv^T(dy[N,OH,OW,Cout]); wb = dgrad-packed buffer from yolo_conv_pack_weights(mode 1)

@@ -22,6 +22,10 @@ struct ConvGeom {
     float* stats;   // forward only: [8][2][Cd] fp32 accumulator for BatchNorm batch statistics, or null
     const void* acc2;   // accumulating launches only: a SECOND tensor (same pixels and channels as dst, row stride ld2) added
     int ld2;            // to the result as well -- dst = conv + dst + acc2 (C3K2: the chunk's gradient fan-in), or null
+    // inference epilogue (Model.fuse(): BatchNorm folded into weights + bias, model_blocks.py:36-37): dst = act(conv + bias) + res
+    int act;            // YOLO_ACT_IDENTITY / YOLO_ACT_SILU, applied after the bias
+    const void* res;    // optional residual (same pixels / channels as dst, row stride ldr) added after the activation, or null
+    int ldr;
 };
 
 static inline int round_up32(int k) { return (k + 31) / 32 * 32; }

@@ -162,6 +162,7 @@ __global__ __launch_bounds__((TH / 4) * (BN / 64) * 64) void k_conv_halo(GeomDev
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
                 if (ACC) {
                     float o[4];
                     load_pack<T, 4>(drow + c, o);

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                    if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
                     if (ACC) {
                         float o[4];
                         load_pack<T, 4>(drow + c, o);

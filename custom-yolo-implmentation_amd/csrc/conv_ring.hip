@@ -33,6 +33,9 @@ struct RingGeom {
     float* stats;
     const void* acc2;           // ACC launches: second accumulate source (row stride ld2) or null
     int ld2;
+    int act;                    // inference epilogue (see ConvGeom)
+    const void* res;
+    int ldr;
     RingSub sub[4];
 };
 
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256) void k_conv_ring(RingGeom g, const T* __restri
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                    if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
                     if (ACC) {
                         float o[4];
                         load_pack<T, 4>(drow + c, o);
@@ -398,6 +402,7 @@ int ring_conv_launch(const ConvGeom* gs, int n, const long* wm_off, long wm_elem
     d.N = g0.N; d.Hs = g0.Hs; d.Ws = g0.Ws; d.Cs = g0.Cs; d.lds = g0.lds; d.Hd = g0.Hd; d.Wd = g0.Wd; d.Cd = g0.Cd; d.ldd = g0.ldd;
     d.ostep = g0.ostep; d.sstride = g0.sstride; d.stats = g0.stats;
     d.acc2 = g0.acc2; d.ld2 = g0.ld2;
+    d.act = g0.act; d.res = g0.res; d.ldr = g0.ldr;
     d.spt = (g0.Cs + t.bk - 1) / t.bk;
     d.ntile_n = (g0.Cd + t.bn - 1) / t.bn;
     d.wm_elems = (int)wm_elems;

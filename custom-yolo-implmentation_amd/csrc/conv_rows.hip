@@ -185,6 +185,7 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
                 if (ACC) {
                     float o[4];
                     load_pack<T, 4>(drow + c, o);

@@ -526,6 +526,18 @@ class ConvBias(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def _frozen_packed(weight, k, stride, T):
+    """Forward-packed matrix of a FROZEN weight (a fused conv's: requires_grad False), packed once and kept on the parameter
+    until it is written to (version counter) or computed in another dtype."""
+    hit = getattr(weight, "_yolo_packed", None)
+    if hit is not None and hit[0] == (weight._version, weight.data_ptr(), T):
+        return hit[1]
+    wp = ops.pack_weights(weight, k, stride, 0, T)
+    if not weight.requires_grad:
+        weight._yolo_packed = ((weight._version, weight.data_ptr(), T), wp)
+    return wp
+
+
 def fused_conv_act(x, weight, bias, k, stride, depthwise, act, res=None, out=None):
     """Conv with BN folded in (Model.fuse(), src/model/model_blocks.py:36-37): act(conv(x) + b) (+ res).
     Inference-only like the reference's fused conv (requires_grad False); no autograd node."""
@@ -535,13 +547,19 @@ def fused_conv_act(x, weight, bias, k, stride, depthwise, act, res=None, out=Non
         cout = weight.shape[0]
         b32 = _f32(bias)
         if not depthwise and act == ACT_IDENTITY and res is None:
-            return ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), b32, cout, k, stride, out=out)
+            return ops.conv_fwd(x, _frozen_packed(weight, k, stride, T), b32, cout, k, stride, out=out)
+        res = None if res is None else _as_nhwc(res, T)
         if depthwise:
             y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9))
         else:
-            y = ops.conv_fwd(x, ops.pack_weights(weight, k, stride, 0, T), None, cout, k, stride)
+            # bias + SiLU + residual in the conv's own epilogue: one launch, one pass (16-bit MFMA path)
+            wp = _frozen_packed(weight, k, stride, T)
+            y = ops.conv_fwd_act(x, wp, b32, cout, k, stride, act, res, out) if T in _LOWP and x.is_cuda else None
+            if y is not None:
+                return y
+            y = ops.conv_fwd(x, wp, None, cout, k, stride)
         one = ops.fill_(torch.empty(cout, dtype=torch.float32, device=x.device), 1.0)
-        return ops.bn_act_fwd(y, one, b32, act, None if res is None else _as_nhwc(res, T), out)
+        return ops.bn_act_fwd(y, one, b32, act, res, out)
 
 
 class Cat(torch.autograd.Function):

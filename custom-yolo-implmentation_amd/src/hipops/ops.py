@@ -232,6 +232,20 @@ def conv_fwd(x, wp, bias, cout, k, stride, stats_acc=None, out=None):
     return y
 
 
+def conv_fwd_act(x, wp, bias, cout, k, stride, act, res=None, out=None):
+    """act(conv(x) + bias) (+ res) in one launch (the fused inference block); None when the shape has no MFMA kernel."""
+    n, cin, h, w, ldx = geom(x)
+    oh, ow = conv_out_hw(h, w, k, stride)
+    y = _dest(out, n, cout, oh, ow, x.dtype, x.device)
+    ldr = geom(res)[4] if res is not None else 0
+    rc = lib.query("yolo_conv2d_fwd_act", _p(x), ldx, _p(wp), _p(bias), _p(res), ldr, _p(y), geom(y)[4], n, h, w, cin, oh, ow, cout, k,
+                   stride, int(act), dt(x), _stream(x))
+    if rc == 1:
+        return None
+    lib.status(rc, "yolo_conv2d_fwd_act")
+    return y
+
+
 BN_REPL = 8
 
 

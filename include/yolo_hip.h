@@ -87,6 +87,8 @@ int yolo_copy_job_fill(void* jobs_host, int index, const void* src, int src_dtyp
 long yolo_copy_jobs_finalize(void* jobs_host, int njobs);
 int yolo_multi_copy(const void* jobs_dev, int njobs, long nchunks, float scale, hipStream_t st);
 int yolo_conv2d_fwd(const void* x, int ldx, const void* wp, const float* bias, void* y, int ldy, float* stats_acc, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);
+/* inference (Model.fuse(), model_blocks.py:36-37): y = act(conv(x) + bias) (+ res) in one launch; returns 1 = no MFMA kernel for this shape, nothing launched */
+int yolo_conv2d_fwd_act(const void* x, int ldx, const void* wp, const float* bias, const void* res, int ldr, void* y, int ldy, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int act, int dtype, hipStream_t st);
 int yolo_conv2d_dgrad(const void* dy, int lddy, const void* wb, void* dx, int lddx, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int accumulate, int dtype, int algo, hipStream_t st);
 /* dx = dgrad + dx + acc2 in one epilogue (a three-way gradient fan-in, stride 1): see model_blocks.py C3K2 */
 int yolo_conv2d_dgrad_acc2(const void* dy, int lddy, const void* wb, void* dx, int lddx, const void* acc2, int ld2, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int dtype, int algo, hipStream_t st);

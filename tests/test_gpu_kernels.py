@@ -382,6 +382,35 @@ def test_attention(dtype, heads, dk, dh, h, w):
     check(dq0, emu.attn_bwd(qkv, o_ref, d_o, None, lse_ref, heads, dk, dh, scale), dtype, "attn dqkv (d_vp None)", mult=4.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,h,w,k,s", [(64, 128, 80, 80, 1, 1),      # k_conv_mfma (large-map 1x1)
+                                             (256, 128, 20, 20, 1, 1),     # k_conv_ring (small-map 1x1)
+                                             (64, 64, 40, 40, 3, 1),       # k_conv_rows (3x3 on a 40-wide map)
+                                             (128, 128, 80, 80, 3, 1),     # k_conv_halo (3x3, two 64-channel tiles)
+                                             (32, 64, 37, 41, 3, 2),       # stride 2, partial tiles
+                                             (72, 40, 13, 11, 1, 1)])      # channel counts that do not fill a tile
+def test_fused_inference_conv_bias_silu_residual(dtype, cin, cout, h, w, k, s):
+    """yolo_conv2d_fwd_act: act(conv(x) + bias) (+ residual) in the conv's own epilogue (Model.fuse() blocks) == conv, then the
+    element-wise pass, for SiLU / identity, with / without a residual that is a channel slice of a wider buffer."""
+    o = ops()
+    n = 2
+    x = nhwc(rnd(n, cin, h, w, seed=80).to(dtype))
+    wt = rnd(cout, cin, k, k, seed=81, scale=(cin * k * k) ** -0.5)
+    bias = rnd(cout, seed=82, scale=0.5)
+    oh, ow = o.conv_out_hw(h, w, k, s)
+    res = nhwc(rnd(n, cout, oh, ow, seed=83).to(dtype), 16)
+    wp = o.pack_weights(wt.to(DEV), k, s, 0, dtype)
+    ref_y = torch.nn.functional.conv2d(x.float(), wt.to(dtype).float(), bias, s, k // 2)
+    for act in (1, 0):
+        for r in (None, res):
+            got = o.conv_fwd_act(dev(x), wp, bias.to(DEV), cout, k, s, act, None if r is None else dev(r))
+            assert got is not None, "no MFMA kernel took this shape"
+            want = torch.nn.functional.silu(ref_y) if act else ref_y
+            if r is not None:
+                want = want + r.float()
+            check(got, want, dtype, f"conv_fwd_act act={act} res={r is not None}", mult=2.0)
+
+
 # ------------------------------------------------------------------------------------------ loss
 def _pack(gts):
     from src.model.losses import PackedTargets

@@ -269,3 +269,26 @@ def test_config5_model_half_preset_l_1280_fp16_inference_vs_fp32_oracle():
     assert float((y.float().cpu() - y_ref.float()).abs().max()) <= 2.0 ** -9 * float(y_ref.float().abs().max())   # fp16 decode
     assert len(dets) == 1 and dets[0].shape == want[0].shape and dets[0].shape[0] == 300
     assert torch.equal(dets[0][:, 5].cpu().float(), want[0][:, 5].float())          # same classes in the same order
+
+
+@pytest.mark.parametrize("precision", ["float16", "bfloat16"])
+def test_fused_inference_equals_unfused_eval(precision):
+    """Model.fuse() in 16 bit: every dense Conv block is ONE launch (bias + SiLU + residual in the conv epilogue, frozen
+    weights packed once) -- against the unfused eval model (conv, BatchNorm coefficients, element-wise pass) on the same
+    input, and against the fp32 oracle."""
+    cfg = ob.PRESETS["s"]
+    dt = getattr(torch, precision)
+    img = torch.randn(2, 3, 320, 320, generator=torch.Generator().manual_seed(23))
+    plain, fused = _model(seed=7, cfg=cfg).eval(), _model(seed=7, cfg=cfg).eval().fuse()
+    with torch.no_grad(), torch.autocast("cuda", dtype=dt):
+        p0 = plain(img.cuda())[0]
+        p1 = fused(img.cuda())[0]
+        p2 = fused(img.cuda())[0]                      # second call: the cached packed weights
+    ps = ParamStore(7)
+    with torch.no_grad():
+        p_ref, _, _ = ob.model_forward(ps, img, cfg["width"], cfg["depth"], cfg["csp"], 80, training=False)
+    e01, e1r, e0r = _rel(p1, p0), _rel(p1, p_ref), _rel(p0, p_ref)
+    print(f"\n[fused inference {precision}] fused vs unfused {e01:.2e}; vs fp32 oracle: fused {e1r:.2e}, unfused {e0r:.2e}")
+    assert torch.equal(p1, p2)
+    tol = 2e-2 if precision == "float16" else 8e-2
+    assert e1r < tol and e1r < 2 * e0r + 1e-3
