@@ -62,17 +62,7 @@ def side_stream(dev):
     """The one auxiliary HIP stream per device (graph capture of more forked streams is not reliable on this stack)."""
     side = _SIDE.get(dev)
     if side is None:
-        mask = os.environ.get("YOLO_SIDE_CU_MASK")         # experiment: e.g. "55555555" = every other CU (one 32-bit word, repeated x8)
-        if mask:
-            import ctypes
-            from . import lib
-            words = (ctypes.c_uint * 8)(*([int(mask, 16)] * 8))
-            out = ctypes.c_void_p()
-            with torch.cuda.device(dev):
-                lib.call("yolo_stream_create_cu_mask", ctypes.cast(words, ctypes.c_void_p), 8, ctypes.cast(ctypes.byref(out), ctypes.c_void_p))
-            side = _SIDE[dev] = torch.cuda.ExternalStream(out.value, device=dev)
-        else:
-            side = _SIDE[dev] = torch.cuda.Stream(dev)
+        side = _SIDE[dev] = torch.cuda.Stream(dev)
     return side
 
 

@@ -46,8 +46,6 @@ typedef struct ihipStream_t* hipStream_t;
 
 /* hash of this header's prototypes at build time; the loader refuses a library built against another header */
 long yolo_abi_hash(void);
-/* experiment (YOLO_SIDE_CU_MASK): a stream restricted to the CUs whose bits are set in mask[mask_words]; host pointers */
-int yolo_stream_create_cu_mask(const unsigned int* mask, int mask_words, void** stream_out);
 
 /* ---- layout / copies (replace .view/.transpose/torch.cat/.chunk copies: head.py:87,119, model_blocks.py:92,123-125,156,249-252, neck.py:41-44) */
 int yolo_memset0(void* p, size_t bytes, hipStream_t st);
