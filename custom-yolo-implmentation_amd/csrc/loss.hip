@@ -2,18 +2,19 @@
 //
 //   preds  [N][64+nc][A]  (T, anchor index fastest)  ->  out[3] = {total, mean_dfl, mean_cls} (fp32)
 //                                                        dpreds [N][64+nc][A] (T) = d total / d preds
-// Launch chain (one stream):
-//   k_decode   : per (n,a) softmax-expectation of the 4x16 DFL logits -> centre-xywh pixels (fp32 pbox)
-//   k_assign   : per GT, argmin over anchors of the distance to the predicted centre, evaluated the way
-//                torch.cdist does for >25 columns ( |a|^2 + |b|^2 - 2ab via a k-ordered fma chain,
-//                clamp, sqrt ) so near-ties resolve as in the reference; first minimum wins
-//   k_dense    : quality-focal term with an all-zero target for every class logit (+ its gradient),
-//                zero gradient for the 64 box logits; per-block partial sums (deterministic)
-//   k_matched  : per image, per matched anchor: DFL cross-entropy pair and its gradient, the quirk IoU
-//                (b1_y2 = h + cy/2, losses.py:20), the soft target at (anchor, class) of the LAST GT
-//                mapped there (losses.py:261), and the IoU gradient that autograd hands to EVERY GT
-//                (also those that lost the slot) back through box decode into the box logits
-//   k_finish   : partials -> the three scalars
+// TWO launches (round 3; six before: decode, assign, zero fill, dense, matched, finish):
+//   k_front    : heterogeneous grid.  Blocks [0, DB): per (n,a) softmax-expectation of the 4x16 DFL logits -> centre-xywh
+//                pixels (fp32 pbox).  Blocks [DB, DB+nblk): quality-focal term with an all-zero target for every class logit
+//                (+ its gradient), zero gradient for the 64 box logits; per-block partial sums (deterministic).  The two
+//                halves are independent and share the launch (and the chip) instead of two launches back to back.
+//   k_back     : one block per image.  (1) assignment: per GT, argmin over the image's anchors of the distance to the
+//                predicted centre, evaluated the way torch.cdist does for >25 columns ( |a|^2 + |b|^2 - 2ab via a k-ordered
+//                fma chain, clamp, sqrt ) so near-ties resolve as in the reference; first minimum wins; one wave per GT.
+//                (2) per matched anchor: DFL cross-entropy pair and its gradient, the quirk IoU (b1_y2 = h + cy/2,
+//                losses.py:20), the soft target at (anchor, class) of the LAST GT mapped there (losses.py:261), and the IoU
+//                gradient that autograd hands to EVERY GT (also those that lost the slot) back through box decode into the
+//                box logits.  (3) the block that finishes LAST (a ticket counter) turns the partials into the three
+//                scalars, summing in a fixed order.
 // fp32 arithmetic, no fma contraction in this file (built with -ffp-contract=off) so the box decode
 // follows the reference's operation order.
 #include "common.h"
@@ -29,9 +30,9 @@ struct LossDims {
 };
 
 template <typename T>
-__global__ void k_decode(LossDims d, const T* __restrict__ preds, const T* __restrict__ anchors,
-                         const T* __restrict__ strides, float4* __restrict__ pbox) {
-    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+__device__ __forceinline__ void decode_block(const LossDims& d, int block, const T* __restrict__ preds, const T* __restrict__ anchors,
+                                             const T* __restrict__ strides, float4* __restrict__ pbox) {
+    long i = block * (long)blockDim.x + threadIdx.x;
     if (i >= (long)d.N * d.A) return;
     int a = (int)(i % d.A);
     long n = i / d.A;
@@ -55,16 +56,10 @@ __global__ void k_decode(LossDims d, const T* __restrict__ preds, const T* __res
     pbox[i] = make_float4((x1 + x2) / 2.f, (y1 + y2) / 2.f, x2 - x1, y2 - y1);
 }
 
-// grid = G rows of the gt buffer; rows past the live count gt_off[N] (a buffer with spare capacity, refilled between
-// replays of a captured step) do nothing
-__global__ void k_assign(int A, const float4* __restrict__ pbox, const float* __restrict__ gt,
-                         const int* __restrict__ gt_img, const int* __restrict__ gt_off, int N, int* __restrict__ idx) {
-    __shared__ float sd[4];
-    __shared__ int si[4];
-    const int j = blockIdx.x;
-    if (j >= gt_off[N]) return;
+// assignment of GT row j (of image n) by ONE wave: argmin over the image's anchors, lowest index among equal distances,
+// NaN wins like torch.argmin; every lane returns the winner
+__device__ __forceinline__ int assign_wave(int A, const float4* __restrict__ pb, const float* __restrict__ gt, int j, int lane) {
     const float gx = gt[j * 5 + 0], gy = gt[j * 5 + 1];
-    const float4* pb = pbox + (long)gt_img[j] * A;
     const float an = __fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy));
     const float m2x = -2.f * gx, m2y = -2.f * gy;
     float best = INFINITY;
@@ -78,15 +73,16 @@ __global__ void k_assign(int A, const float4* __restrict__ pbox, const float* __
         float dist = __fsqrt_rn(fmaxf(acc, 0.f));
         if (dist < best || (dist != dist && best == best)) { best = dist; bi = a; }   // NaN wins like argmin
     };
-    // four boxes per thread in flight, considered in the same order as one at a time (33 dependent round trips for 8400
-    // anchors were the kernel's 16 us)
-    const int bd = blockDim.x;
-    int a = threadIdx.x;
-    for (; a + 3 * bd < A; a += 4 * bd) {
-        const float4 b0 = pb[a], b1 = pb[a + bd], b2 = pb[a + 2 * bd], b3 = pb[a + 3 * bd];
-        consider(a, b0); consider(a + bd, b1); consider(a + 2 * bd, b2); consider(a + 3 * bd, b3);
+    // eight boxes per lane in flight, considered in index order
+    int a = lane;
+    for (; a + 7 * 64 < A; a += 8 * 64) {
+        float4 b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = pb[a + u * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) consider(a + u * 64, b[u]);
     }
-    for (; a < A; a += bd) consider(a, pb[a]);
+    for (; a < A; a += 64) consider(a, pb[a]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         float ob = __shfl_xor(best, o, 64);
@@ -94,17 +90,7 @@ __global__ void k_assign(int A, const float4* __restrict__ pbox, const float* __
         bool take = (ob < best) || (ob == best && oi < bi) || (ob != ob && (best == best || oi < bi));
         if (take) { best = ob; bi = oi; }
     }
-    if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) {
-            float ob = sd[w];
-            int oi = si[w];
-            bool take = (ob < best) || (ob == best && oi < bi) || (ob != ob && (best == best || oi < bi));
-            if (take) { best = ob; bi = oi; }
-        }
-        idx[j] = bi;
-    }
+    return bi;
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -135,13 +121,13 @@ __device__ __forceinline__ void qfl_elem0(float x, float& val, float& dx) {
 // images are spread evenly over the grid, four per thread in flight (one 32-bit division per packet finds its image);
 // the box region only gets its zero gradient written.
 template <typename T, int V>
-__global__ __launch_bounds__(256) void k_dense(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds, float coef,
-                                               double* __restrict__ partial, const float* __restrict__ grad_scale) {
+__device__ __forceinline__ void dense_block(const LossDims& d, int block, int nblk, const T* __restrict__ preds, T* __restrict__ dpreds,
+                                            float coef, double* __restrict__ partial, const float* __restrict__ grad_scale) {
     __shared__ float red[4];
     if (grad_scale) coef *= *grad_scale;                     // fp16 loss scaling: applied in fp32, before the one rounding
     const int Cp = 4 * REG + d.nc;
     const int P = d.nc * (d.A / V), Z = 4 * REG * (d.A / V);  // packets per image: class region, box region (host: A % V == 0)
-    const int nthr = gridDim.x * 256, gtid = blockIdx.x * 256 + threadIdx.x;
+    const int nthr = nblk * 256, gtid = block * 256 + threadIdx.x;
     constexpr int U = 4;
     float lsum = 0.f;
     const long per_img = (long)Cp * d.A;
@@ -183,21 +169,44 @@ __global__ __launch_bounds__(256) void k_dense(LossDims d, const T* __restrict__
     lsum = wave_sum(lsum);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (double)red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) partial[block] = (double)red[0] + red[1] + red[2] + red[3];
 }
+
+// blocks [0, DB): box decode; blocks [DB, DB + nblk): the dense class pass.  Block 0 also clears the ticket counter k_back's
+// last block is found with.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_front(LossDims d, int DB, int nblk, const T* __restrict__ preds, const T* __restrict__ anchors,
+                                               const T* __restrict__ strides, float4* __restrict__ pbox, T* __restrict__ dpreds,
+                                               float coef, double* __restrict__ partial, const float* __restrict__ grad_scale,
+                                               unsigned int* __restrict__ ticket) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;
+    if ((int)blockIdx.x < DB) decode_block<T>(d, blockIdx.x, preds, anchors, strides, pbox);
+    else dense_block<T, V>(d, (int)blockIdx.x - DB, nblk, preds, dpreds, coef, partial, grad_scale);
+}
+
+__device__ void finish_scalars(const LossDims& d, const double* partial, int nblk, const double* img_dfl, const double* img_cls_fix,
+                               float* __restrict__ out);
 
 // one workgroup per image; wave w takes GTs w, w+4, ...; lane = (side, bin) of the 64 box logits
 template <typename T>
-__global__ __launch_bounds__(256) void k_matched(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds,
-                                                 const T* __restrict__ anchors, const T* __restrict__ strides,
-                                                 const float4* __restrict__ pbox, const float* __restrict__ gt,
-                                                 const int* __restrict__ gt_off, const int* __restrict__ idx,
-                                                 double* __restrict__ img_dfl, double* __restrict__ img_cls_fix,
-                                                 const float* __restrict__ grad_scale) {
+__global__ __launch_bounds__(256) void k_back(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds,
+                                              const T* __restrict__ anchors, const T* __restrict__ strides,
+                                              const float4* __restrict__ pbox, const float* __restrict__ gt,
+                                              const int* __restrict__ gt_off, int* __restrict__ idx,
+                                              double* __restrict__ img_dfl, double* __restrict__ img_cls_fix,
+                                              const float* __restrict__ grad_scale, const double* __restrict__ partial, int nblk,
+                                              unsigned int* __restrict__ ticket, float* __restrict__ out) {
     __shared__ double w_dfl[4], w_cls[4];
+    __shared__ unsigned int my_ticket;
     const float gsc = grad_scale ? *grad_scale : 1.f;
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g0 = gt_off[n], M = gt_off[n + 1] - g0;
+    // ---- (1) assignment of this image's GTs, one wave per GT; idx stays in global memory (tests read it back)
+    for (int j = wave; j < M; j += 4) {
+        const int bi = assign_wave(d.A, pbox + (long)n * d.A, gt, g0 + j, lane);
+        if (lane == 0) idx[g0 + j] = bi;
+    }
+    __syncthreads();
     const int Cp = 4 * REG + d.nc;
     const T* pn = preds + (long)n * Cp * d.A;
     T* dn = dpreds ? dpreds + (long)n * Cp * d.A : nullptr;
@@ -292,13 +301,20 @@ __global__ __launch_bounds__(256) void k_matched(LossDims d, const T* __restrict
     if (threadIdx.x == 0) {
         img_dfl[n] = w_dfl[0] + w_dfl[1] + w_dfl[2] + w_dfl[3];
         img_cls_fix[n] = w_cls[0] + w_cls[1] + w_cls[2] + w_cls[3];
+        __threadfence();                                        // the two sums before the ticket
+        my_ticket = atomicAdd(ticket, 1u);
     }
+    __syncthreads();
+    // ---- (3) the block whose ticket is the last one sums everything, in a fixed order (independent of which block it is)
+    if (my_ticket != (unsigned)d.N - 1u || wave != 0) return;
+    __threadfence();
+    finish_scalars(d, partial, nblk, img_dfl, img_cls_fix, out);
 }
 
-__global__ void k_finish(LossDims d, const double* __restrict__ partial, int nblk, const double* __restrict__ img_dfl,
-                         const double* __restrict__ img_cls_fix, float* __restrict__ out) {
-    // one wave: lanes sum strided slices (a single thread walking 2048 partials took 113 us), then a
-    // fixed-order butterfly -- still deterministic
+// one wave: lanes sum strided slices (a single thread walking 2048 partials took 113 us), then a fixed-order butterfly --
+// deterministic.  The per-image sums were written by other blocks of this launch: agent-scope atomic loads.
+__device__ void finish_scalars(const LossDims& d, const double* partial, int nblk, const double* img_dfl, const double* img_cls_fix,
+                               float* __restrict__ out) {
     double cls = 0.0, dfl = 0.0;
     {   // eight partials per lane in flight (one load per trip was one round trip per trip: 32 of them, 10.8 us); the sums are
         // taken in the same order as before
@@ -312,7 +328,10 @@ __global__ void k_finish(LossDims d, const double* __restrict__ partial, int nbl
         }
         for (; b < nblk; b += 64) cls += partial[b];
     }
-    for (int n = threadIdx.x; n < d.N; n += 64) { cls += img_cls_fix[n]; dfl += img_dfl[n]; }
+    for (int n = threadIdx.x; n < d.N; n += 64) {
+        cls += __hip_atomic_load(img_cls_fix + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dfl += __hip_atomic_load(img_dfl + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         cls += __shfl_xor(cls, o, 64);
@@ -338,11 +357,12 @@ constexpr int DENSE_BLOCKS = 2048;
 
 extern "C" {
 
-// workspace bytes: pbox (16 B per anchor) + idx (4 B per GT) + partials
+// workspace bytes: pbox (16 B per anchor) + idx (4 B per GT) + partials + the ticket counter
 size_t yolo_loss_workspace_bytes(int N, int A, int G) {
     size_t b = (size_t)N * A * 16;
     b += ((size_t)(G > 0 ? G : 1) * 4 + 15) / 16 * 16;
     b += (size_t)(DENSE_BLOCKS + 2 * N) * 8;
+    b += 16;
     return b;
 }
 
@@ -355,6 +375,8 @@ size_t yolo_loss_workspace_bytes(int N, int A, int G) {
 int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A,
                       const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl,
                       float lambda_cls, void* dpreds, float* out, void* workspace, const float* grad_scale, hipStream_t st) {
+    (void)gt_img;                                            // (the per-image blocks walk gt_off; kept in the signature)
+    if (N < 1) return YOLO_ERR_ARG;
     LossDims d{N, A, nc, lambda_dfl, lambda_cls};
     char* ws = (char*)workspace;
     float4* pbox = (float4*)ws;
@@ -364,25 +386,23 @@ int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* stride
     double* partial = (double*)ws;
     double* img_dfl = partial + DENSE_BLOCKS;
     double* img_fix = img_dfl + N;
+    unsigned int* ticket = (unsigned int*)(img_fix + N);
     const long NA = (long)N * A;
     const long elems = NA * (64 + nc);
     const float coef = lambda_cls / (float)N / (float)A;
+    const int DB = ceil_div(NA, 256);
     YOLO_DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((k_decode<T>), dim3(ceil_div(NA, 256)), dim3(256), 0, st, d, (const T*)preds,
-                           (const T*)anchors, (const T*)strides, pbox);
-        if (G > 0) hipLaunchKernelGGL(k_assign, dim3(G), dim3(256), 0, st, A, pbox, gt, gt_img, gt_off, N, idx);
         constexpr int VV = vec_of<T>::N;
         bool vec = (A % VV == 0) && ((uintptr_t)preds % 16 == 0) && (!dpreds || (uintptr_t)dpreds % 16 == 0);
         int nblk = (int)((elems / (vec ? VV : 1) + 255) / 256);
         if (nblk > DENSE_BLOCKS) nblk = DENSE_BLOCKS;
         if (nblk < 1) nblk = 1;
-        int rc = yolo_zero_async(partial, DENSE_BLOCKS * sizeof(double), st);
-        if (rc) return rc;
-        if (vec) hipLaunchKernelGGL((k_dense<T, VV>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial, grad_scale);
-        else hipLaunchKernelGGL((k_dense<T, 1>), dim3(nblk), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, coef, partial, grad_scale);
-        hipLaunchKernelGGL((k_matched<T>), dim3(N), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, (const T*)anchors,
-                           (const T*)strides, pbox, gt, gt_off, idx, img_dfl, img_fix, grad_scale);
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, d, partial, DENSE_BLOCKS, img_dfl, img_fix, out);
+        if (vec) hipLaunchKernelGGL((k_front<T, VV>), dim3(DB + nblk), dim3(256), 0, st, d, DB, nblk, (const T*)preds, (const T*)anchors,
+                                    (const T*)strides, pbox, (T*)dpreds, coef, partial, grad_scale, ticket);
+        else hipLaunchKernelGGL((k_front<T, 1>), dim3(DB + nblk), dim3(256), 0, st, d, DB, nblk, (const T*)preds, (const T*)anchors,
+                                (const T*)strides, pbox, (T*)dpreds, coef, partial, grad_scale, ticket);
+        hipLaunchKernelGGL((k_back<T>), dim3(N), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, (const T*)anchors,
+                           (const T*)strides, pbox, gt, gt_off, idx, img_dfl, img_fix, grad_scale, partial, nblk, ticket, out);
     });
     return YOLO_LAUNCH_CHECK();
 }
