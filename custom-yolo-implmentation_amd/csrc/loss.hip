@@ -2,19 +2,19 @@
 //
 //   preds  [N][64+nc][A]  (T, anchor index fastest)  ->  out[3] = {total, mean_dfl, mean_cls} (fp32)
 //                                                        dpreds [N][64+nc][A] (T) = d total / d preds
-// TWO launches (round 3; six before: decode, assign, zero fill, dense, matched, finish):
+// THREE launches (round 3; six before: decode, assign, zero fill, dense, matched, finish):
 //   k_front    : heterogeneous grid.  Blocks [0, DB): per (n,a) softmax-expectation of the 4x16 DFL logits -> centre-xywh
 //                pixels (fp32 pbox).  Blocks [DB, DB+nblk): quality-focal term with an all-zero target for every class logit
 //                (+ its gradient), zero gradient for the 64 box logits; per-block partial sums (deterministic).  The two
 //                halves are independent and share the launch (and the chip) instead of two launches back to back.
-//   k_back     : one block per image.  (1) assignment: per GT, argmin over the image's anchors of the distance to the
-//                predicted centre, evaluated the way torch.cdist does for >25 columns ( |a|^2 + |b|^2 - 2ab via a k-ordered
-//                fma chain, clamp, sqrt ) so near-ties resolve as in the reference; first minimum wins; one wave per GT.
-//                (2) per matched anchor: DFL cross-entropy pair and its gradient, the quirk IoU (b1_y2 = h + cy/2,
-//                losses.py:20), the soft target at (anchor, class) of the LAST GT mapped there (losses.py:261), and the IoU
-//                gradient that autograd hands to EVERY GT (also those that lost the slot) back through box decode into the
-//                box logits.  (3) the block that finishes LAST (a ticket counter) turns the partials into the three
-//                scalars, summing in a fixed order.
+//   k_assign   : one wave per GT: argmin over the image's anchors of the distance to the predicted centre, evaluated the way
+//                torch.cdist does for >25 columns ( |a|^2 + |b|^2 - 2ab via a k-ordered fma chain, clamp, sqrt ) so
+//                near-ties resolve as in the reference; first minimum wins.
+//   k_back     : one block per image.  Per matched anchor: DFL cross-entropy pair and its gradient, the quirk IoU (b1_y2 =
+//                h + cy/2, losses.py:20), the soft target at (anchor, class) of the LAST GT mapped there (losses.py:261), and
+//                the IoU gradient that autograd hands to EVERY GT (also those that lost the slot) back through box decode
+//                into the box logits.  The block that finishes LAST (a ticket counter, cleared by k_front) turns the
+//                partials into the three scalars, summing in a fixed order.
 // fp32 arithmetic, no fma contraction in this file (built with -ffp-contract=off) so the box decode
 // follows the reference's operation order.
 #include "common.h"
@@ -91,6 +91,19 @@ __device__ __forceinline__ int assign_wave(int A, const float4* __restrict__ pb,
         if (take) { best = ob; bi = oi; }
     }
     return bi;
+}
+
+// grid = G rows of the gt buffer, one wave per row (four rows per block); rows past the live count gt_off[N] (a buffer with
+// spare capacity, refilled between replays of a captured step) do nothing.  (Folding this into k_back -- each image's block
+// assigning its own GTs one after the other -- was measured: 146 us for the loss instead of 117; the rows need the chip's
+// parallelism, not one block per image.)
+__global__ __launch_bounds__(256) void k_assign(int A, const float4* __restrict__ pbox, const float* __restrict__ gt,
+                                                const int* __restrict__ gt_img, const int* __restrict__ gt_off, int N,
+                                                int* __restrict__ idx) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= gt_off[N]) return;
+    const int bi = assign_wave(A, pbox + (long)gt_img[j] * A, gt, j, lane);
+    if (lane == 0) idx[j] = bi;
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -192,7 +205,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_back(LossDims d, const T* __restrict__ preds, T* __restrict__ dpreds,
                                               const T* __restrict__ anchors, const T* __restrict__ strides,
                                               const float4* __restrict__ pbox, const float* __restrict__ gt,
-                                              const int* __restrict__ gt_off, int* __restrict__ idx,
+                                              const int* __restrict__ gt_off, const int* __restrict__ idx,
                                               double* __restrict__ img_dfl, double* __restrict__ img_cls_fix,
                                               const float* __restrict__ grad_scale, const double* __restrict__ partial, int nblk,
                                               unsigned int* __restrict__ ticket, float* __restrict__ out) {
@@ -201,12 +214,7 @@ __global__ __launch_bounds__(256) void k_back(LossDims d, const T* __restrict__ 
     const float gsc = grad_scale ? *grad_scale : 1.f;
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g0 = gt_off[n], M = gt_off[n + 1] - g0;
-    // ---- (1) assignment of this image's GTs, one wave per GT; idx stays in global memory (tests read it back)
-    for (int j = wave; j < M; j += 4) {
-        const int bi = assign_wave(d.A, pbox + (long)n * d.A, gt, g0 + j, lane);
-        if (lane == 0) idx[g0 + j] = bi;
-    }
-    __syncthreads();
+
     const int Cp = 4 * REG + d.nc;
     const T* pn = preds + (long)n * Cp * d.A;
     T* dn = dpreds ? dpreds + (long)n * Cp * d.A : nullptr;
@@ -375,7 +383,6 @@ size_t yolo_loss_workspace_bytes(int N, int A, int G) {
 int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* strides, int dtype, int N, int nc, int A,
                       const float* gt, const int* gt_off, const int* gt_img, int G, float lambda_dfl,
                       float lambda_cls, void* dpreds, float* out, void* workspace, const float* grad_scale, hipStream_t st) {
-    (void)gt_img;                                            // (the per-image blocks walk gt_off; kept in the signature)
     if (N < 1) return YOLO_ERR_ARG;
     LossDims d{N, A, nc, lambda_dfl, lambda_cls};
     char* ws = (char*)workspace;
@@ -401,6 +408,7 @@ int yolo_loss_dfl_qfl(const void* preds, const void* anchors, const void* stride
                                     (const T*)strides, pbox, (T*)dpreds, coef, partial, grad_scale, ticket);
         else hipLaunchKernelGGL((k_front<T, 1>), dim3(DB + nblk), dim3(256), 0, st, d, DB, nblk, (const T*)preds, (const T*)anchors,
                                 (const T*)strides, pbox, (T*)dpreds, coef, partial, grad_scale, ticket);
+        if (G > 0) hipLaunchKernelGGL(k_assign, dim3(ceil_div(G, 4)), dim3(256), 0, st, A, pbox, gt, gt_img, gt_off, N, idx);
         hipLaunchKernelGGL((k_back<T>), dim3(N), dim3(256), 0, st, d, (const T*)preds, (T*)dpreds, (const T*)anchors,
                            (const T*)strides, pbox, gt, gt_off, idx, img_dfl, img_fix, grad_scale, partial, nblk, ticket, out);
     });
