@@ -93,6 +93,12 @@ class ShardState:
         """The full flat vector (fp32) from every rank's fp32 shard of it -- a collective."""
         shard = shard.detach().float().contiguous()
         if self.group and self.world > 1:
+            if dist.get_backend() != "nccl":                 # gloo: sum of zero-padded slices
+                full = torch.zeros(self.total, dtype=torch.float32, device=shard.device)
+                lo = self.rank * self.shard_elems
+                full[lo:lo + self.shard_elems].copy_(shard)
+                dist.all_reduce(full)
+                return full
             full = torch.empty(self.total, dtype=torch.float32, device=shard.device)
             dist.all_gather_into_tensor(full, shard)
             return full
@@ -169,10 +175,11 @@ class ShardedStepRunner(TrainStepRunner):
             self.g_shard.copy_(self.flat_g[: self.shard_elems])
             return
         if self.sum_then_scale:
-            g32 = self.flat_g.float()                        # gloo: no low-precision reduce-scatter either
-            out = torch.empty(self.shard_elems, dtype=torch.float32, device=g32.device)
-            dist.reduce_scatter_tensor(out, g32)
-            self.g_shard.copy_(out / self.world)
+            # gloo (tests, rehearsals on one card): no AVG, no low-precision reduce-scatter -- an fp32 all-reduce, this rank's slice
+            g32 = self.flat_g.float()
+            dist.all_reduce(g32)
+            lo = self.rank * self.shard_elems
+            self.g_shard.copy_(g32[lo:lo + self.shard_elems] / self.world)
         else:
             dist.reduce_scatter_tensor(self.g_shard, self.flat_g, op=dist.ReduceOp.AVG)
 
@@ -192,7 +199,15 @@ class ShardedStepRunner(TrainStepRunner):
                 self.p_shard.copy_(self.master.data)
 
     def _all_gather(self):
-        if self.group:
+        if not self.group:
+            return
+        if self.sum_then_scale:                              # gloo: every rank contributes its slice of a zero vector, summed
+            full = torch.zeros(self.total, dtype=torch.float32, device=self.flat_p.device)
+            lo = self.rank * self.shard_elems
+            full[lo:lo + self.shard_elems].copy_(self.p_shard)
+            dist.all_reduce(full)
+            self.flat_p.copy_(full)
+        else:
             dist.all_gather_into_tensor(self.flat_p, self.p_shard)
 
     def _fwd_bwd_pack(self, images, packed):

@@ -552,6 +552,93 @@ def _ddp_rank(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _shard_rank(rank, world, port, out):
+    """One of two ranks sharing the GPU over gloo: `--mode fsdp2` with `native_shard: true` end to end -- prepare_fsdp2_model,
+    get_optimizer (shards the model), train() through ShardedTraining (captured graphs around the two collectives), rank 1 with
+    one oversize batch (every rank steps it eagerly), validation, the gathered checkpoint."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, ".."), os.path.join(here, "..", "custom-yolo-implmentation_amd")):
+        sys.path.insert(0, os.path.abspath(p))
+    import tempfile
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    from oracle.params import det_fill_
+    from src.model.losses import YoloDFLQFLoss
+    from src.model.model_builder import Model
+    from src.training import train_model as tm
+    from src.training.utils_train import get_optimizer, prepare_fsdp2_model
+    m = Model(**NANO, num_classes=80)
+    det_fill_(m.state_dict(), 9)                        # FSDP starts from identical weights on every rank
+    model = prepare_fsdp2_model(model=m, device_id=0, config={"precision": "bfloat16", "native_shard": True}, world_size=world, device="cuda")
+
+    class Loader(list):
+        sampler = None
+
+    def batches(n, seed, big_at=None):
+        g = torch.Generator().manual_seed(seed)
+        out_ = Loader()
+        for i in range(n):
+            cnt = [300, 300] if i == big_at else [3 + (i % 3), 1 + rank]
+            img = torch.randn(2, 3, 160, 160, generator=g)
+            tg = [{"boxes": torch.cat([torch.rand(c, 2, generator=g) * 160, torch.rand(c, 2, generator=g) * 60 + 8,
+                                       torch.randint(0, 80, (c, 1), generator=g).float()], 1)} for c in cnt]
+            out_.append((img, tg))
+        return out_
+    tr = batches(5, 7 + rank, big_at=3 if rank == 1 else None)
+    va = batches(2, 50 + rank)
+    opt, sched = get_optimizer(model, lr=1e-3, weight_decay=1e-4, patience=3, factor=0.5)
+    st = model._native_shard["state"]
+    before = st.master.detach().clone()
+    seen = []
+    orig = tm.ShardedTraining.step
+
+    def spy(self, images, boxes):
+        ld = orig(self, images, boxes)
+        seen.append((self.captured, self.dirty, self.runner.graph is not None))
+        return ld
+    tm.ShardedTraining.step = spy
+    with tempfile.TemporaryDirectory() as d:
+        tm.train(model=model, train_loader=tr, val_loader=va, optimizer=opt, scheduler=sched, criterion=YoloDFLQFLoss(num_classes=80),
+                 initial_epoch=0, num_epochs=1, device=0, num_classes=80, rank=rank, checkpoint_dir=d, distributed_mode="fsdp2",
+                 precision="bfloat16", conf_threshold=0.01)
+        dist.barrier()
+        ck = torch.load(os.path.join(d, "model_epoch_1.pth"), map_location="cpu", weights_only=False) if rank == 0 else None
+    flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()]).cpu()      # the gathered bf16 compute copies
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    moved = float((st.master.detach() - before).abs().max())
+    if rank == 0:
+        bare = Model(**NANO, num_classes=80)
+        bare.load_state_dict(ck["model_state"])
+        ck_vs_lowp = max(float((dict(bare.named_parameters())[k].float() - p.detach().float().cpu()).abs().max() /
+                               p.detach().float().abs().max().clamp_min(1e-6)) for k, p in model.named_parameters() if p.requires_grad)
+        torch.save(dict(wdiff=float((both[0] - both[1]).abs().max()), finite=bool(torch.isfinite(flat).all()), seen=seen, moved=moved,
+                        shard_frac=st.master.numel() / st.total, ck_vs_lowp=ck_vs_lowp), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_native_sharded_training_two_ranks_sharing_the_gpu_over_gloo(tmp_path):
+    """config 4's native route on N = 2 as far as a one-GPU box can go (two processes on the card, gloo instead of RCCL): both
+    ranks end the epoch with identical parameters, each owns half of the master vector, the step was captured and the
+    oversize batch of rank 1 sent BOTH ranks through the eager step, the gathered fp32 checkpoint matches the bf16 copies."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "shard.pt")
+    mp.spawn(_shard_rank, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["finite"] and r["wdiff"] == 0.0 and r["moved"] > 0, r
+    assert abs(r["shard_frac"] - 0.5) < 1e-9
+    steps = r["seen"]
+    assert len(steps) == 5 and steps[0][0] and steps[0][2] and steps[3][1] and not steps[4][1], steps
+    assert r["ck_vs_lowp"] < 2.0 ** -7, r           # fp32 masters vs their bf16 images
+
+
 @pytest.mark.timeout(600)
 def test_captured_ddp_two_ranks_sharing_the_gpu_over_gloo(tmp_path):
     """The drop-in default on N = 2 (as far as a one-GPU box can go: two processes on the card, gloo instead of RCCL):
