@@ -6,7 +6,7 @@ import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-marks = [i for i, r in enumerate(rows) if "k_finish" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_back" in r["Kernel_Name"]]
 k = len(marks) - 3
 seg = rows[marks[k] + 1:marks[k + 1] + 1]
 t0 = int(seg[0]["Start_Timestamp"])

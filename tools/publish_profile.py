@@ -1,13 +1,15 @@
 """gpurun_out/<TAG>/ (written by tools/final_profile.sh on the GPU box) -> the tracked evidence files under profiles/:
 r2_final_summary.md, r2_final_pmc_hbm.md, r2_final_pmc.json (read by bench.py for `roofline.traffic`),
-r2_final_kernel_stats.csv, r2_final_bench.json.     python tools/publish_profile.py r2/final2"""
+r2_final_kernel_stats.csv, r2_final_bench.json.     python tools/publish_profile.py r2/final2 [r3_final "Round 3"]"""
 import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(ROOT, "gpurun_out", sys.argv[1])
 P = os.path.join(ROOT, "profiles")
+PRE = sys.argv[2] if len(sys.argv) > 2 else "r2_final"
+ROUND = sys.argv[3] if len(sys.argv) > 3 else "Round 2"
 rd = lambda n: open(os.path.join(F, n)).read()
-shutil.copy(os.path.join(F, "stats", "run_kernel_stats.csv"), os.path.join(P, "r2_final_kernel_stats.csv"))
-shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, "r2_final_bench.json"))
+shutil.copy(os.path.join(F, "stats", "run_kernel_stats.csv"), os.path.join(P, PRE + "_kernel_stats.csv"))
+shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, PRE + "_bench.json"))
 b = json.loads(rd("bench.json"))
 groups = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_groups.py"), os.path.join(F, "fetch", "f_counter_collection.csv"),
                          os.path.join(F, "write", "w_counter_collection.csv"), "3"], capture_output=True, text=True).stdout
@@ -24,14 +26,14 @@ conv = next(v for k, v in rows.items() if k.startswith("conv fwd+dgrad"))
 total = rows.get("all kernels", {}).get("total_gb")
 json.dump({"kernel": "conv_mfma(fwd+dgrad)", "hbm_bytes_per_launch": conv["mb_per_launch"] * 1e6, "launches_per_step": conv["launches_per_step"],
            "fetch_gb_per_step_x2_corrected": conv["fetch_gb"], "write_gb_per_step": conv["write_gb"], "algorithmic_gb_per_step": 8.69,
-           "source": "profiles/r2_final_pmc_hbm.md: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction",
-           "groups": rows}, open(os.path.join(P, "r2_final_pmc.json"), "w"), indent=1)
+           "source": "profiles/" + PRE + "_pmc_hbm.md: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction",
+           "groups": rows}, open(os.path.join(P, PRE + "_pmc.json"), "w"), indent=1)
 r = b["roofline"]
 chains = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "chain_breakdown.py"), os.path.join(F, "stats", "run_kernel_trace.csv"), "32"],
                         capture_output=True, text=True).stdout
 gaps = rd("gaps.txt")
 sq = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sq_table.py"), os.path.join(F, "sq.log"), "3"], capture_output=True, text=True).stdout
-open(os.path.join(P, "r2_final_sq_pmc.md"), "w").write(f"""# Round 2 (final state) — SQ counters of the step's MFMA kernel families (MI355X, preset s @640 bf16, 32 img)
+open(os.path.join(P, PRE + "_sq_pmc.md"), "w").write(f"""# {ROUND} (final state) — SQ counters of the step's MFMA kernel families (MI355X, preset s @640 bf16, 32 img)
 
 `tools/pmc_kernel.sh`: six separate `rocprofv3 --kernel-trace --pmc <four SQ counters>` passes of
 `python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra` (eager launches, three steps per pass), summed per
@@ -45,15 +47,15 @@ Raw sums:
 ```
 {rd("sq.log")}```
 """)
-open(os.path.join(P, "r2_final_summary.md"), "w").write(f"""# Round 2 (final state) — rocprofv3 summary, MI355X, preset s @640 bf16, 32 img, graph-captured train step
+open(os.path.join(P, PRE + "_summary.md"), "w").write(f"""# {ROUND} (final state) — rocprofv3 summary, MI355X, preset s @640 bf16, 32 img, graph-captured train step
 
 Produced by `bash tools/final_profile.sh` on one MI355X box and `python tools/publish_profile.py`: the default `python3 bench.py`
-line (`profiles/r2_final_bench.json`: {b['value']:.0f} img/s, {b['ms_per_step']:.2f} ms/step; dominant MFMA kernel group conv fwd+dgrad
+line (`profiles/{PRE}_bench.json`: {b['value']:.0f} img/s, {b['ms_per_step']:.2f} ms/step; dominant MFMA kernel group conv fwd+dgrad
 {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of 2.5 PF over {r['launches']} leaf calls, {r['avg_launch_us']:.1f} us average), then
 
     rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra
 
-whose per-kernel statistics are `profiles/r2_final_kernel_stats.csv` (whole run: capture warm-up, 25 replays, the instrumented
+whose per-kernel statistics are `profiles/{PRE}_kernel_stats.csv` (whole run: capture warm-up, 25 replays, the instrumented
 eager step of the roofline leg).  rocprofv3's average over the conv fwd+dgrad kernels INSIDE the replayed step (k_conv_mfma +
 k_conv_ring + k_conv_halo + k_conv_rows + k_dgrad2_patch) is in the chain table below; the live
 leaf timing counts such a layer as one call.
@@ -68,10 +70,10 @@ leaf timing counts such a layer as one call.
 ```
 {gaps}```
 
-## HBM traffic from PMC counters -> `profiles/r2_final_pmc_hbm.md`
+## HBM traffic from PMC counters -> `profiles/{PRE}_pmc_hbm.md`
 
 {groups}""")
-open(os.path.join(P, "r2_final_pmc_hbm.md"), "w").write(f"""# Round 2 (final state) — HBM traffic from PMC counters (MI355X, preset s @640 bf16, 32 img, one train step)
+open(os.path.join(P, PRE + "_pmc_hbm.md"), "w").write(f"""# {ROUND} (final state) — HBM traffic from PMC counters (MI355X, preset s @640 bf16, 32 img, one train step)
 
 Collected as `MI355X_MICROARCH.md` (§HBM, §rocprofv3 PMC slots) prescribes: two separate passes, kernel trace only,
 

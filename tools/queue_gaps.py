@@ -4,7 +4,7 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 thr = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
-marks = [i for i, r in enumerate(rows) if "k_finish" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_back" in r["Kernel_Name"]]
 k = len(marks) - 3
 seg = rows[marks[k] + 1:marks[k + 1] + 1]
 ia = next(i for i, r in enumerate(seg) if "k_adamw" in r["Kernel_Name"] and "tick" not in r["Kernel_Name"])

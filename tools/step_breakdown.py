@@ -1,8 +1,8 @@
-"""One training step's kernels (between two k_finish launches of the loss) from a rocprofv3 kernel trace."""
+"""One training step's kernels (between two k_back launches (the last kernel of the loss)) from a rocprofv3 kernel trace."""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-fin = [i for i, r in enumerate(rows) if 'k_finish' in r['Kernel_Name']]
+fin = [i for i, r in enumerate(rows) if 'k_back' in r['Kernel_Name']]
 seg = rows[fin[-3]:fin[-2]]
 span = (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e6
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg) / 1e6

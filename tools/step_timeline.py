@@ -1,4 +1,4 @@
-"""One replayed step out of a rocprofv3 kernel trace (csv): the kernels between two consecutive loss `k_finish` launches, in
+"""One replayed step out of a rocprofv3 kernel trace (csv): the kernels between two consecutive loss `k_back` launches, in
 start order, with queue, duration, grid and the per-queue busy time -- to see which launches carry the main stream.
     python tools/step_timeline.py kernel_trace.csv [step_index] [top]"""
 import collections
@@ -8,7 +8,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "k_finish" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_back" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 3
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 seg = rows[marks[k] + 1:marks[k + 1] + 1]

@@ -3,7 +3,7 @@ kernel that starts after each gap (cross-stream fork/join latency shows up here)
 import csv, sys, collections, statistics
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-fin = [i for i, r in enumerate(rows) if 'k_finish' in r['Kernel_Name']]
+fin = [i for i, r in enumerate(rows) if 'k_back' in r['Kernel_Name']]
 seg = rows[fin[-3]:fin[-2]]
 iv = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '')[:44], r['Queue_Id']) for r in seg]
 span = iv[-1][1] - iv[0][0]
