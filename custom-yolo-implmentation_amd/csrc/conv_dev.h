@@ -1,6 +1,7 @@
 // Device-side pieces shared by the conv kernels (conv_mfma.hip, conv_halo.hip): MFMA wrappers, the packed
 // geometry passed by value, the XCD-aware tile order and the 16-lane row reduction.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 #include "conv_geom.h"
 
@@ -38,6 +39,7 @@ struct GeomDev {           // ConvGeom with the tap offsets packed (no dynamic i
     float* stats;                // optional [8][2][Cd] batch-statistics accumulator (forward of a BN conv)
     const void* acc2;            // ACC launches: second accumulate source (row stride ld2) or null
     int ld2;
+    int wide;                    // 16-byte epilogue stores where the destination allows (YOLO_CONV_WIDE=0: the 8-byte form, A/B runs)
     int act;                     // inference epilogue: 1 = SiLU after the bias
     const void* res;             // inference epilogue: residual added after the activation (row stride ldr) or null
     int ldr;
@@ -95,6 +97,8 @@ inline GeomDev to_dev(const ConvGeom& g) {
     d.stats = g.stats;
     d.acc2 = g.acc2; d.ld2 = g.ld2;
     d.act = g.act; d.res = g.res; d.ldr = g.ldr;
+    static const int wide_env = [] { const char* e = getenv("YOLO_CONV_WIDE"); return e ? atoi(e) : 1; }();
+    d.wide = wide_env;
     d.tap_inner = 0;
     d.dma = 1;      // LDS-DMA staging: level or a few % ahead of register staging on every shape of tools/conv_tune.py
     for (int t = 0; t < g.ntaps; ++t) {

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         // pair swapped between them (ds_bpermute, lane ^ 16) leaves the even lane with 8 consecutive channels of block j and
         // the odd lane with 8 of block j + 1 -- half as many (and twice as wide) write requests per wave instruction.  The
         // write-heavy 1x1 layers were at 2.7-3.2 TB/s with the 8-byte form (512 -> 128 @80x80 data gradient: 97 us for 52).
-        const bool wide = sizeof(T) == 2 && (WN % 2 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (g.ldd % 8 == 0);
+        const bool wide = sizeof(T) == 2 && (WN % 2 == 0) && g.wide && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (g.ldd % 8 == 0);
         auto block_values = [&](int i, int j, long pix, T* drow, bool live, float (&v)[4]) {
             const int c = cd0 + crow + j * 16 + cq;
 #pragma unroll
