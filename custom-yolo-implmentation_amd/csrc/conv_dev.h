@@ -88,6 +88,69 @@ __device__ __forceinline__ void fused_epilogue(float (&v)[4], int act, const voi
     }
 }
 
+// Epilogue of one output pixel: the WN 16-channel blocks of accumulator row `a` (lane: channels cq .. cq+3 of every block,
+// pixel = the lane's fr) -> bias, inference act / residual, accumulate sources, store.  Shared by the five MFMA conv kernels.
+// 16-byte stores where the destination allows it (base 16-byte aligned, row stride a multiple of 8 channels, G::wide): lanes
+// (fr, fg) and (fr, fg ^ 1) hold neighbouring channel quads of the SAME pixel for every block j; one dword pair swapped
+// between them (lane ^ 16) leaves the even lane with 8 consecutive channels of block j and the odd lane with 8 of block j+1 --
+// half as many, twice as wide write requests per wave instruction (same-box A/B on the step with k_conv_mfma alone:
+// 10.51 -> 10.38 ms; 512 -> 128 @80x80 data gradient 97 -> 78 us).  EVERY lane of the wave must call this (`live` false
+// for pixels outside the map): the exchange is a cross-lane operation.
+template <typename T, int WN, bool ACC, typename G>
+__device__ __forceinline__ void store_pixel_blocks(const G& g, const f32x4 (&a)[WN], const float (&bv)[WN][4], T* __restrict__ dst,
+                                                   long pix, bool live, int cbase, int cq, int lane) {
+    T* drow = dst + pix * g.ldd;
+    auto values = [&](int j, float (&v)[4]) {
+        const int c = cbase + j * 16 + cq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = a[j][r] + bv[j][r];
+        if (!live || c >= g.Cd) return;
+        if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
+        if (ACC) {
+            float o[4];
+            load_pack<T, 4>(drow + c, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += o[r];
+            if (g.acc2 != nullptr) {
+                load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += o[r];
+            }
+        }
+    };
+    const bool wide = sizeof(T) == 2 && (WN % 2 == 0) && g.wide && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (g.ldd % 8 == 0);
+    if (wide) {
+        const bool odd = (lane >> 4) & 1;
+#pragma unroll
+        for (int j = 0; j + 1 < WN; j += 2) {
+            float va[4], vb[4];
+            values(j, va);
+            values(j + 1, vb);
+            pack_t<T, 4> pa, pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pa.v[r] = from_f<T>(va[r]); pb.v[r] = from_f<T>(vb[r]); }
+            const uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+            const uint2 send = odd ? ua : ub;                      // what the partner keeps
+            uint2 recv;
+            recv.x = __shfl_xor(send.x, 16, 64);
+            recv.y = __shfl_xor(send.y, 16, 64);
+            // even lane: block j, channels cq .. cq+7 = own | partner's; odd lane: block j+1, channels cq-4 .. cq+3
+            const uint4 out = odd ? make_uint4(recv.x, recv.y, ub.x, ub.y) : make_uint4(ua.x, ua.y, recv.x, recv.y);
+            const int c8 = cbase + (odd ? j + 1 : j) * 16 + (odd ? cq - 4 : cq);
+            if (live && c8 < g.Cd) *reinterpret_cast<uint4*>(drow + c8) = out;
+        }
+    } else if (live) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int c = cbase + j * 16 + cq;
+            if (c >= g.Cd) continue;            // Cd % 8 == 0 => a group of 4 is all-in or all-out
+            float v[4];
+            values(j, v);
+            store_pack<T, 4>(drow + c, v);
+        }
+    }
+}
+
 inline GeomDev to_dev(const ConvGeom& g) {
     GeomDev d;
     d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd;

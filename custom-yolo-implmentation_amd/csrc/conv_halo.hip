@@ -152,31 +152,8 @@ __global__ __launch_bounds__((TH / 4) * (BN / 64) * 64) void k_conv_halo(GeomDev
     for (int i = 0; i < 4; ++i) {
         const int oy = y0 + wgm * 4 + i;
         const bool pv = oy < g.Hg && ox < g.Wg;
-        if (pv) {
-            const long pix = ((long)n * g.Hd + oy) * (long)g.Wd + ox;
-            T* drow = dst + pix * g.ldd;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = cd0 + crow + j * 16 + cq;
-                if (c >= g.Cd) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-                if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
-                if (ACC) {
-                    float o[4];
-                    load_pack<T, 4>(drow + c, o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += o[r];
-                    if (g.acc2 != nullptr) {
-                        load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += o[r];
-                    }
-                }
-                store_pack<T, 4>(drow + c, v);
-            }
-        } else {
+        store_pixel_blocks<T, 4, ACC>(g, acc[i], bv, dst, pv ? ((long)n * g.Hd + oy) * (long)g.Wd + ox : 0, pv, cd0 + crow, cq, lane);
+        if (!pv) {
             // pixels outside the map must not reach the statistics
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -278,65 +278,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         int b = (int)(qq - t2 * g.Wg);
         int n = (int)(t2 / (unsigned)g.Hg);
         int a = (int)t2 - n * g.Hg;
-        // 16-byte stores where the destination allows it (base 16-byte aligned, row stride a multiple of 8 channels): lanes
-        // (fr, fg) and (fr, fg ^ 1) hold channels 4 fg .. 4 fg + 3 of the SAME pixel for every 16-channel block j; one dword
-        // pair swapped between them (ds_bpermute, lane ^ 16) leaves the even lane with 8 consecutive channels of block j and
-        // the odd lane with 8 of block j + 1 -- half as many (and twice as wide) write requests per wave instruction.  The
-        // write-heavy 1x1 layers were at 2.7-3.2 TB/s with the 8-byte form (512 -> 128 @80x80 data gradient: 97 us for 52).
-        const bool wide = sizeof(T) == 2 && (WN % 2 == 0) && g.wide && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (g.ldd % 8 == 0);
-        auto block_values = [&](int i, int j, long pix, T* drow, bool live, float (&v)[4]) {
-            const int c = cd0 + crow + j * 16 + cq;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-            if (!live || c >= g.Cd) return;
-            if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
-            if (ACC) {
-                float o[4];
-                load_pack<T, 4>(drow + c, o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += o[r];
-                if (g.acc2 != nullptr) {
-                    load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += o[r];
-                }
-            }
-        };
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const bool live = q < total_pix;
             const long pix = live ? ((long)n * g.Hd + a * g.ostep + g.ooff_h) * (long)g.Wd + b * g.ostep + g.ooff_w : 0;
-            T* drow = dst + pix * g.ldd;
-            if (wide) {
-#pragma unroll
-                for (int j = 0; j + 1 < WN; j += 2) {
-                    float va[4], vb[4];
-                    block_values(i, j, pix, drow, live, va);
-                    block_values(i, j + 1, pix, drow, live, vb);
-                    pack_t<T, 4> pa, pb;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { pa.v[r] = from_f<T>(va[r]); pb.v[r] = from_f<T>(vb[r]); }
-                    const uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
-                    const bool odd = (lane >> 4) & 1;
-                    const uint2 send = odd ? ua : ub;                      // what the partner keeps
-                    uint2 recv;
-                    recv.x = __shfl_xor(send.x, 16, 64);
-                    recv.y = __shfl_xor(send.y, 16, 64);
-                    // even lane: block j, channels cq .. cq+7 = own | partner's; odd lane: block j+1, channels cq-4 .. cq+3
-                    const uint4 out = odd ? make_uint4(recv.x, recv.y, ub.x, ub.y) : make_uint4(ua.x, ua.y, recv.x, recv.y);
-                    const int c8 = cd0 + crow + (odd ? j + 1 : j) * 16 + (odd ? cq - 4 : cq);
-                    if (live && c8 < g.Cd) *reinterpret_cast<uint4*>(drow + c8) = out;
-                }
-            } else if (live) {
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const int c = cd0 + crow + j * 16 + cq;
-                    if (c >= g.Cd) continue;            // Cd % 8 == 0 => a group of 4 is all-in or all-out
-                    float v[4];
-                    block_values(i, j, pix, drow, true, v);
-                    store_pack<T, 4>(drow + c, v);
-                }
-            }
+            store_pixel_blocks<T, WN, ACC>(g, acc[i], bv, dst, pix, live, cd0 + crow, cq, lane);
             q += 16;
             b += 16;
             while (b >= g.Wg) {

@@ -33,6 +33,7 @@ struct RingGeom {
     float* stats;
     const void* acc2;           // ACC launches: second accumulate source (row stride ld2) or null
     int ld2;
+    int wide;                   // 16-byte epilogue stores (see store_pixel_blocks)
     int act;                    // inference epilogue (see ConvGeom)
     const void* res;
     int ldr;
@@ -216,31 +217,9 @@ __global__ __launch_bounds__(256) void k_conv_ring(RingGeom g, const T* __restri
         int a = (int)t2 - n * sb.Hg;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            if (q < sb.npix) {
-                const long pix = ((long)n * g.Hd + a * g.ostep + sb.ooff_h) * (long)g.Wd + b * g.ostep + sb.ooff_w;
-                T* drow = dst + pix * g.ldd;
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const int c = cd0 + crow + j * 16 + cq;
-                    if (c >= g.Cd) continue;                  // Cd % 8 == 0 => a group of 4 is all-in or all-out
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-                    if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
-                    if (ACC) {
-                        float o[4];
-                        load_pack<T, 4>(drow + c, o);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += o[r];
-                        if (g.acc2 != nullptr) {
-                            load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += o[r];
-                        }
-                    }
-                    store_pack<T, 4>(drow + c, v);
-                }
-            }
+            const bool live = q < sb.npix;
+            const long pix = live ? ((long)n * g.Hd + a * g.ostep + sb.ooff_h) * (long)g.Wd + b * g.ostep + sb.ooff_w : 0;
+            store_pixel_blocks<T, WN, ACC>(g, acc[i], bv, dst, pix, live, cd0 + crow, cq, lane);
             q += 16;
             b += 16;
             while (b >= sb.Wg) {
@@ -403,6 +382,7 @@ int ring_conv_launch(const ConvGeom* gs, int n, const long* wm_off, long wm_elem
     d.ostep = g0.ostep; d.sstride = g0.sstride; d.stats = g0.stats;
     d.acc2 = g0.acc2; d.ld2 = g0.ld2;
     d.act = g0.act; d.res = g0.res; d.ldr = g0.ldr;
+    d.wide = to_dev(g0).wide;
     d.spt = (g0.Cs + t.bk - 1) / t.bk;
     d.ntile_n = (g0.Cd + t.bn - 1) / t.bn;
     d.wm_elems = (int)wm_elems;

@@ -175,31 +175,9 @@ __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __
     for (int i = 0; i < 5; ++i) {
         const int p = (wgm * 5 + i) * 16 + fr, pr = p / W, pc = p - pr * W;
         const int oy = y0 + pr, ox = x0 + pc;
-        if (oy < g.Hg && ox < g.Wg) {
-            const long pix = ((long)n * g.Hd + oy) * (long)g.Wd + ox;
-            T* drow = dst + pix * g.ldd;
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int c = cd0 + crow + j * 16 + cq;
-                if (c >= g.Cd) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-                if (g.act | (g.res != nullptr)) fused_epilogue<T>(v, g.act, g.res, pix * g.ldr + c);
-                if (ACC) {
-                    float o[4];
-                    load_pack<T, 4>(drow + c, o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += o[r];
-                    if (g.acc2 != nullptr) {
-                        load_pack<T, 4>((const T*)g.acc2 + pix * g.ld2 + c, o);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += o[r];
-                    }
-                }
-                store_pack<T, 4>(drow + c, v);
-            }
-        } else {
+        const bool live = oy < g.Hg && ox < g.Wg;
+        store_pixel_blocks<T, WN, ACC>(g, acc[i], bv, dst, live ? ((long)n * g.Hd + oy) * (long)g.Wd + ox : 0, live, cd0 + crow, cq, lane);
+        if (!live) {
             // pixels outside the map must not reach the statistics
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -23,6 +23,10 @@ struct Up2Geom {
     int N, Hs, Ws, Cs, lds, Hd, Wd, Cd, ldd;
     int wm_off[4], Kpad[4];    // class matrices inside the packed buffer (elements)
     int wm_elems;
+    // what store_pixel_blocks reads (no bias / activation / second source in a data gradient of this kind)
+    int wide, act, ldr, ld2;
+    const void* res;
+    const void* acc2;
 };
 
 // the nine (class, tap) products in step order; taps of a class in conv_taps' order: (dh, dw) = (t / nw, t % nw)
@@ -181,29 +185,15 @@ __global__ __launch_bounds__((TH / WM) * (BN / 32) * 64) __attribute__((amdgpu_w
     const int cq = fg * 4;
     const int b = x0 + fr;
     const int Hg = g.Hd >> 1, Wg = g.Wd >> 1;
+    const float zero_bias[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int a = y0 + wgm * WM + i;
-        if (a >= Hg || b >= Wg) continue;
+        const bool live = a < Hg && b < Wg;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const long pix = ((long)n * g.Hd + 2 * a + (c >> 1)) * (long)g.Wd + 2 * b + (c & 1);
-            T* drow = dst + pix * g.ldd;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ch = cd0 + crow + j * 16 + cq;
-                if (ch >= g.Cd) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[c][i][j][r];
-                if (ACC) {
-                    float o[4];
-                    load_pack<T, 4>(drow + ch, o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += o[r];
-                }
-                store_pack<T, 4>(drow + ch, v);
-            }
+            const long pix = live ? ((long)n * g.Hd + 2 * a + (c >> 1)) * (long)g.Wd + 2 * b + (c & 1) : 0;
+            store_pixel_blocks<T, 2, ACC>(g, acc[c][i], zero_bias, dst, pix, live, cd0 + crow, cq, lane);
         }
     }
 }
@@ -271,6 +261,7 @@ int up2_conv_launch(const ConvGeom* gs, int variant, const long* wm_off, long wm
     d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd; d.ldd = g.ldd;
     for (int c = 0; c < 4; ++c) { d.wm_off[c] = (int)wm_off[c]; d.Kpad[c] = gs[c].Kpad; }
     d.wm_elems = (int)wm_elems;
+    d.wide = to_dev(gs[0]).wide; d.act = 0; d.res = nullptr; d.ldr = 0; d.acc2 = nullptr; d.ld2 = 0;
     if (g.N * g.Hs * g.Ws == 0) return YOLO_OK;
 #define UP2_T(T_)                                                                                       \
     return variant == 16 ? launch_up2<T_, 16, 32, 4, 3>(d, src, wm, dst, accumulate, st)                \
