@@ -5,6 +5,8 @@
 #include "common.h"
 #include "conv_geom.h"
 
+int conv_wide_flag();            // conv_mfma.hip: 16-byte epilogue stores on (default) / off (YOLO_CONV_WIDE=0, yolo_conv_wide_set)
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -160,8 +162,7 @@ inline GeomDev to_dev(const ConvGeom& g) {
     d.stats = g.stats;
     d.acc2 = g.acc2; d.ld2 = g.ld2;
     d.act = g.act; d.res = g.res; d.ldr = g.ldr;
-    static const int wide_env = [] { const char* e = getenv("YOLO_CONV_WIDE"); return e ? atoi(e) : 1; }();
-    d.wide = wide_env;
+    d.wide = conv_wide_flag();
     d.tap_inner = 0;
     d.dma = 1;      // LDS-DMA staging: level or a few % ahead of register staging on every shape of tools/conv_tune.py
     for (int t = 0; t < g.ntaps; ++t) {

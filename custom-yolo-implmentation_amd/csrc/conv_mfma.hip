@@ -486,6 +486,14 @@ extern "C" int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma, int 
     return YOLO_OK;
 }
 
+static int& wide_state() {
+    static int v = [] { const char* e = getenv("YOLO_CONV_WIDE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+int conv_wide_flag() { return wide_state(); }
+// test / A-B override of the 16-byte epilogue stores (store_pixel_blocks): 1 on, 0 off
+extern "C" int yolo_conv_wide_set(int on) { wide_state() = on ? 1 : 0; return YOLO_OK; }
+
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst) {
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;
     if (g.Cs % 8 || g.lds % 8 || g.Cd % 8 || g.ldd % 4) return 0;

@@ -39,6 +39,7 @@ def _reset_tuning():
     lib().call("yolo_conv_tune_set", 0, -1, -1, -1, -1, 0, 0, 0)
     lib().call("yolo_wgrad_tune_set", 0, 0, 0, 0)
     lib().call("yolo_wgrad_tune_pf", 0)
+    lib().call("yolo_conv_wide_set", 1)
 
 
 def rnd(shape, seed, scale=1.0, dtype=None):
@@ -321,6 +322,55 @@ def test_config2_forward_and_dgrad_calls_elementwise(config2_calls):
     assert not failures, "\n".join(failures)
     # the step must have exercised the wide tiles and the halo kernel (what the bench's time is made of)
     assert any(p // 1000 == 3 for p in plans) and any(p // 1000 == 2 for p in plans), plans
+
+
+def test_config2_wide_and_narrow_epilogue_stores_are_bit_identical_on_every_image(config2_calls):
+    """The 16-byte epilogue (store_pixel_blocks: a lane-pair exchange, then one 16-byte store) against the 8-byte form over the
+    WHOLE output of every distinct forward / data-gradient call of preset s @640 at 32 images -- same values, only the store
+    instructions differ, so the two must be bit-identical on all 32 images, accumulate forms included.  (The element-wise tests
+    compare five images per call against the CPU reference; the stride-2 patch kernel was found wrong in a few workgroups of
+    images they do not look at, and keeps the 8-byte form: a mismatch here names the kernel family to switch back.)"""
+    o, q = ops(), lib().query
+    failures, plans = [], {}
+    cases = [("fwd",) + c[:9] + (False,) for c in sorted(config2_calls["fwd"])] + [("dgrad",) + c for c in sorted(config2_calls["dgrad"])]
+    seen = set()
+    for kind, n, cin, cout, h, w, k, s, ld_a, ld_b, acc in cases:
+        if cin < 8 or cin % 8 or (kind, n, cin, cout, h, w, k, s, ld_a, ld_b, acc) in seen:
+            continue
+        seen.add((kind, n, cin, cout, h, w, k, s, ld_a, ld_b, acc))
+        oh, ow = o.conv_out_hw(h, w, k, s)
+        plan = q("yolo_conv2d_plan", n, h, w, cin, oh, ow, cout, k, s, 1 if kind == "dgrad" else 0, 0, lib().BF16)
+        wt = rnd((cout, cin, k, k), 3, (cin * k * k) ** -0.5).float().to(DEV)
+        if kind == "fwd":
+            src, _, _ = on_dev(rnd((n, cin, h, w), 1), ld_a)
+            wp = o.pack_weights(wt, k, s, 0, BF)
+            run = lambda out: o.conv_fwd(src, wp, None, cout, k, s, None, out=out)
+            shape, ld_out = (n, cout, oh, ow), ld_b
+        else:
+            src, _, _ = on_dev(rnd((n, cout, oh, ow), 1), ld_b)
+            wb = o.pack_weights(wt, k, s, 1, BF)
+            run = lambda out: o.conv_dgrad(src, wb, cin, h, w, k, s, acc_into=out if acc else None) if acc else _dgrad_into(o, src, wb, cin, h, w, k, s, out)
+            shape, ld_out = (n, cin, h, w), ld_a
+        outs = []
+        for wide in (1, 0):
+            lib().call("yolo_conv_wide_set", wide)
+            base = rnd(shape, 5)
+            dst, _, _ = on_dev(base, ld_out)
+            r = run(dst)
+            outs.append((r if r is not None else dst).clone())
+        lib().call("yolo_conv_wide_set", 1)
+        plans[plan // 1000] = plans.get(plan // 1000, 0) + 1
+        if not torch.equal(outs[0], outs[1]):
+            bad = (outs[0] != outs[1])
+            imgs = bad.flatten(1).any(1).nonzero().flatten().tolist()
+            failures.append(f"{kind} {(n, cin, cout, h, w, k, s)} acc={acc} plan {plan}: {int(bad.sum())} elements differ, images {imgs[:8]}")
+    print(f"\n[wide vs narrow stores] {len(seen)} calls, kernel kinds (plan // 1000 -> count): {plans}")
+    assert not failures, "\n".join(failures)
+
+
+def _dgrad_into(o, src, wb, cin, h, w, k, s, out):
+    """plain (non-accumulating) data gradient; the result tensor is the kernel's own allocation"""
+    return o.conv_dgrad(src, wb, cin, h, w, k, s)
 
 
 def test_config2_weight_gradient_calls_elementwise(config2_calls):
