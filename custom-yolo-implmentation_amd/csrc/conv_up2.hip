@@ -261,10 +261,13 @@ int up2_conv_launch(const ConvGeom* gs, int variant, const long* wm_off, long wm
     d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd; d.ldd = g.ldd;
     for (int c = 0; c < 4; ++c) { d.wm_off[c] = (int)wm_off[c]; d.Kpad[c] = gs[c].Kpad; }
     d.wm_elems = (int)wm_elems;
-    // 8-byte stores here: with the 16-byte exchange path this kernel returned wrong values for parity class (1,1) -- always
-    // that class, whichever order the classes are stored in -- in a few waves of a 32-image launch (1-4 images of 32, sometimes
-    // none; never at 4 images; the same binary with the path switched off at run time is exact): sporadic, so timing is
-    // involved, and unexplained; the path stays off for this kernel (tools/dbg_up2.py compares ALL images against ATen).
+    // 8-byte stores here.  With the 16-byte exchange path this kernel returned wrong values for parity class (1,1) -- always that
+    // class, whichever order the classes are stored in -- in a few waves of a 32-image launch (1-6 images of 32 per run, never at
+    // 4 images; the same binary with the path switched off at run time is exact over 36 all-image runs, also beside a second
+    // stream).  At a wrong pixel 2-43 of the 128 channels are off by 0.1-0.5 (values ~1): the size of ONE missing (chunk, tap)
+    // product, i.e. class (1,1)'s accumulators as the epilogue reads them.  128 s_nop or a workgroup barrier in front of the
+    // epilogue change nothing; storing that class once more through the 8-byte path right after makes it WORSE.  Unexplained
+    // (tools/dbg_up2.py, round 3); the exchange path stays off for this kernel.
     d.wide = 0; d.act = 0; d.res = nullptr; d.ldr = 0; d.acc2 = nullptr; d.ld2 = 0;
     if (g.N * g.Hs * g.Ws == 0) return YOLO_OK;
 #define UP2_T(T_)                                                                                       \

@@ -28,6 +28,14 @@ for r in range(reps):
     tot += nb
     if nb:
         idx = bad.nonzero()
+        i0 = idx[0].tolist()
+        v = got[i0[0], :, i0[2], i0[3]]                                  # 128 channels of the first bad pixel
+        d = (ref[i0[0]] - v[:, None, None]).abs().amax(0)                # max channel distance to every pixel of the image
+        m = int(d.argmin()); my, mx = m // w, m % w
+        # channel-wise: which channels are wrong at that pixel, and do they equal the reference at some other channel block?
+        wrong = ((v - ref[i0[0], :, i0[2], i0[3]]).abs() > lim).nonzero().flatten().tolist()
+        print(f"  first bad pixel {i0[0]},{i0[2]},{i0[3]}: {len(wrong)} wrong channels {wrong[:12]}...; nearest reference pixel ({my},{mx}) max-dist {float(d.flatten()[m]):.3f}")
+        print("   got", [round(float(t), 3) for t in v[:8]], "ref", [round(float(t), 3) for t in ref[i0[0], :8, i0[2], i0[3]]])
         print(f"rep {r}: bad {nb}; images {idx[:, 0].unique().tolist()} row parity {sorted(set((idx[:, 2] % 2).tolist()))} col parity {sorted(set((idx[:, 3] % 2).tolist()))}")
 torch.cuda.synchronize()
 print(f"{reps} runs, concurrent load {load}: {tot} bad elements in total")
