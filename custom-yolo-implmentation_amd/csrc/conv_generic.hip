@@ -605,7 +605,7 @@ static dim3 dw_grid(int nrows, int cv) {
 
 // dwconv.hip: the strip kernels for 16-bit tensors with 8-channel alignment (-1 = does not qualify)
 int dw_strip_launch(bool flip, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
-                    int accumulate, float* stats, hipStream_t st);
+                    int accumulate, float* stats, hipStream_t st, const float* bias = nullptr, int act = 0);
 int dw_strip_wgrad_launch(const void* x, int ldx, const void* dy, int ldy, float* partial, int nslab, int N, int H, int W, int C,
                           int dtype, hipStream_t st);
 
@@ -640,6 +640,16 @@ int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy,
 int yolo_dwconv3x3_fwd_stats(const void* x, int ldx, const float* w, void* y, int ldy, float* stats, int N, int H, int W, int C,
                              int dtype, hipStream_t st) {
     const int fast = dw_strip_launch(false, x, ldx, w, y, ldy, N, H, W, C, dtype, 0, stats, st);
+    return fast < 0 ? 1 : fast;
+}
+
+// y = act(dwconv(x) + bias) in one launch: the depthwise blocks of a fused model (Model.fuse(): BatchNorm folded into w and
+// bias).  act: 0 identity, 1 SiLU.  Returns 1 when the strip kernel does not take these tensors (nothing was launched; the
+// caller runs yolo_dwconv3x3_fwd + the element-wise pass).
+int yolo_dwconv3x3_fwd_act(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int H, int W, int C,
+                           int act, int dtype, hipStream_t st) {
+    if (bias == nullptr || (act != 0 && act != 1)) return YOLO_ERR_ARG;
+    const int fast = dw_strip_launch(false, x, ldx, w, y, ldy, N, H, W, C, dtype, 0, nullptr, st, bias, act);
     return fast < 0 ? 1 : fast;
 }
 

@@ -41,6 +41,8 @@ struct DwGeom {
     int nsh;        // row strips per image
     int ncb;        // column blocks per row
     long total;     // strips * column blocks * images
+    const float* bias;   // fused inference (forward only): y = act(conv + bias); nullptr / 0 otherwise
+    int act;
 };
 
 constexpr int OOB = (int)0x80000000;
@@ -116,6 +118,15 @@ __global__ __launch_bounds__(256) void k_dw3x3_strip(DwGeom g, const T* __restri
         for (int o = 0; o < R; ++o) {
             if (h0 + o >= g.H) break;
             T* dst = y + ((long)(n * g.H + h0 + o) * g.W + wc) * g.ldy + ch;
+            if (!FLIP && g.bias != nullptr) {                 // folded BatchNorm (Model.fuse()): bias, then SiLU
+                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ch), b1 = *reinterpret_cast<const float4*>(g.bias + ch + 4);
+                acc[o][0] += b0.x; acc[o][1] += b0.y; acc[o][2] += b0.z; acc[o][3] += b0.w;
+                acc[o][4] += b1.x; acc[o][5] += b1.y; acc[o][6] += b1.z; acc[o][7] += b1.w;
+                if (g.act) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o][j] = acc[o][j] * __frcp_rn(1.f + __expf(-acc[o][j]));
+                }
+            }
             if (accumulate) {                                 // gradient fan-in: add to what another consumer's backward left
                 float prev[8];
                 load_pack<T, 8>(dst, prev);
@@ -244,6 +255,7 @@ bool dw_geom(DwGeom& g, const void* x, int ldx, const void* y, int ldy, int N, i
     g.nsh = (H + R - 1) / R;
     g.ncb = (W + g.ncol - 1) / g.ncol;
     g.total = (long)N * g.nsh * g.ncb;
+    g.bias = nullptr; g.act = 0;
     return g.total > 0;
 }
 
@@ -251,11 +263,13 @@ bool dw_geom(DwGeom& g, const void* x, int ldx, const void* y, int ldy, int N, i
 
 // forward / data gradient; returns -1 when the tensors do not qualify (the caller falls back to the generic kernel)
 int dw_strip_launch(bool flip, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype,
-                    int accumulate, float* stats, hipStream_t st) {
+                    int accumulate, float* stats, hipStream_t st, const float* bias, int act) {
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return -1;
     constexpr int R = 4;
     DwGeom g;
     if (!dw_geom(g, x, ldx, y, ldy, N, H, W, C, R)) return -1;
+    if (bias != nullptr && (flip || stats != nullptr || (reinterpret_cast<uintptr_t>(bias) & 15))) return -1;
+    g.bias = bias; g.act = act;
     const dim3 grid((unsigned)(g.total < 4096 ? g.total : 4096), (unsigned)ceil_div(C / 8, g.cvb));
     const size_t lds = (size_t)g.cvb * 8 * 9 * sizeof(float);
 #define DW_GO(T_, FLIP_) hipLaunchKernelGGL((k_dw3x3_strip<T_, R, FLIP_>), grid, dim3(256), lds, st, g, (const T_*)x, w, (T_*)y, accumulate, stats)

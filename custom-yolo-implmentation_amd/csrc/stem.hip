@@ -75,7 +75,7 @@ constexpr int STEM_IR = 5;          // input rows per channel for TWO output row
 template <typename T, int CT>
 __global__ __launch_bounds__(256) void k_stem_conv(const float* __restrict__ img, const T* __restrict__ wp,
                                                    T* __restrict__ y, int ldy, float* __restrict__ stats, int N, int H,
-                                                   int W, int OH, int OW, int Cout) {
+                                                   int W, int OH, int OW, int Cout, const float* __restrict__ bias, int act) {
     typedef mfma_ops<T> ops;
     typedef typename ops::frag frag;
     // rows[ci*5 + ir][4 + c] = input row 2*oh0 - 1 + ir, column 2*ow0 + c (c in [0, 256)); [..][3] = column 2*ow0 - 1
@@ -164,6 +164,11 @@ __global__ __launch_bounds__(256) void k_stem_conv(const float* __restrict__ img
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[ct][i][r];
+            if (bias != nullptr) {                              // fused inference (BatchNorm folded in): act(conv + b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bias[ct * 16 + kg * 4 + r];
+            }
+            if (act) fused_epilogue<T>(v, act, nullptr, 0);
             store_pack<T, 4>(drow + ct * 16 + kg * 4, v);
         }
     }
@@ -388,10 +393,10 @@ int launch_stem_wgrad(const float* img, const void* dy, int ldy, float* part, in
 
 template <typename T>
 int launch_stem_conv(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW,
-                     int Cout, hipStream_t st) {
+                     int Cout, const float* bias, int act, hipStream_t st) {
     const long blocks = (long)N * ((OH + 1) / 2) * ((OW + STEM_SEG - 1) / STEM_SEG);
     if (blocks <= 0 || blocks > 0x7fffffffL) return YOLO_ERR_ARG;
-#define STEM_CT(CT) hipLaunchKernelGGL((k_stem_conv<T, CT>), dim3((unsigned)blocks), dim3(256), 0, st, img, (const T*)wp, (T*)y, ldy, stats, N, H, W, OH, OW, Cout)
+#define STEM_CT(CT) hipLaunchKernelGGL((k_stem_conv<T, CT>), dim3((unsigned)blocks), dim3(256), 0, st, img, (const T*)wp, (T*)y, ldy, stats, N, H, W, OH, OW, Cout, bias, act)
     switch (Cout / 16) {
         case 1: STEM_CT(1); break;
         case 2: STEM_CT(2); break;
@@ -461,13 +466,17 @@ int yolo_stem_conv_eligible(int img_dtype, int dtype, int Cout) {
 }
 
 // y[N][OH][OW][ld >= Cout] (dtype) = conv3x3 stride 2 pad 1 of img (N,3,H,W) fp32 NCHW with wp = yolo_stem_pack_weights
-// output ([Cout][32], dtype); stats: optional [8][2][Cout] BatchNorm accumulator (sum, sum of squares of the stored values)
+// output ([Cout][32], dtype); stats: optional [8][2][Cout] BatchNorm accumulator (sum, sum of squares of the stored values).
+// bias (optional fp32 [Cout]) and act (0 identity, 1 SiLU): the fused-inference form act(conv + bias) of Model.fuse();
+// not combined with stats (the statistics are those of the raw conv output).
 int yolo_stem_conv_fwd(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW,
-                       int Cout, int dtype, hipStream_t st) {
+                       int Cout, const float* bias, int act, int dtype, hipStream_t st) {
+    if ((bias != nullptr || act) && stats != nullptr) return YOLO_ERR_ARG;
+    if (act != 0 && act != 1) return YOLO_ERR_ARG;
     if (!yolo_stem_conv_eligible(YOLO_F32, dtype, Cout) || ldy < Cout) return YOLO_ERR_ARG;
     if (OH != (H - 1) / 2 + 1 || OW != (W - 1) / 2 + 1) return YOLO_ERR_ARG;
-    if (dtype == YOLO_BF16) return launch_stem_conv<bf16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, st);
-    return launch_stem_conv<f16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, st);
+    if (dtype == YOLO_BF16) return launch_stem_conv<bf16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, bias, act, st);
+    return launch_stem_conv<f16_t>(img, wp, y, ldy, stats, N, H, W, OH, OW, Cout, bias, act, st);
 }
 
 // number of partial matrices yolo_stem_wgrad may write: partial = fp32 [yolo_stem_wgrad_slabs()][Cout][32] scratch

@@ -538,19 +538,39 @@ def _frozen_packed(weight, k, stride, T):
     return wp
 
 
+def _frozen_stem(weight, T):
+    """[cout][32] stem matrix of a frozen weight, kept on the parameter like _frozen_packed."""
+    hit = getattr(weight, "_yolo_stem_packed", None)
+    if hit is not None and hit[0] == (weight._version, weight.data_ptr(), T):
+        return hit[1]
+    wp = ops.stem_pack_weights(weight, T)
+    if not weight.requires_grad:
+        weight._yolo_stem_packed = ((weight._version, weight.data_ptr(), T), wp)
+    return wp
+
+
 def fused_conv_act(x, weight, bias, k, stride, depthwise, act, res=None, out=None):
     """Conv with BN folded in (Model.fuse(), src/model/model_blocks.py:36-37): act(conv(x) + b) (+ res).
     Inference-only like the reference's fused conv (requires_grad False); no autograd node."""
     with torch.no_grad():
         T = compute_dtype(x, weight)
-        x = _as_nhwc(x, T)
         cout = weight.shape[0]
         b32 = _f32(bias)
+        if (not depthwise and weight.shape[1] == 3 and k == 3 and stride == 2 and res is None and out is None and x.is_cuda
+                and x.dtype == torch.float32 and ops.stem_conv_eligible(x, T, cout)):
+            # the stem: straight from the NCHW fp32 image, bias + SiLU in the epilogue (Cin = 3 has no MFMA conv kernel)
+            return ops.stem_conv_fwd(x, _frozen_stem(weight, T), cout, T, None, b32, act)
+        x = _as_nhwc(x, T)
         if not depthwise and act == ACT_IDENTITY and res is None:
             return ops.conv_fwd(x, _frozen_packed(weight, k, stride, T), b32, cout, k, stride, out=out)
         res = None if res is None else _as_nhwc(res, T)
         if depthwise:
-            y = ops.dw_fwd(x, _f32(weight).reshape(cout, 9))
+            w9 = _f32(weight).reshape(cout, 9)
+            if res is None and out is None and T in _LOWP and x.is_cuda:
+                y = ops.dw_fwd_act(x, w9, b32, act)
+                if y is not None:
+                    return y
+            y = ops.dw_fwd(x, w9)
         else:
             # bias + SiLU + residual in the conv's own epilogue: one launch, one pass (16-bit MFMA path)
             wp = _frozen_packed(weight, k, stride, T)

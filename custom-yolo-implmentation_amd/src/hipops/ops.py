@@ -354,15 +354,17 @@ def stem_conv_eligible(img, dtype, cout):
         bool(lib.query("yolo_stem_conv_eligible", dt(img), dt(dtype), cout))
 
 
-def stem_conv_fwd(img, wp, cout, dtype, stats_acc=None):
+def stem_conv_fwd(img, wp, cout, dtype, stats_acc=None, bias=None, act=0):
     """(N,3,H,W) fp32 NCHW image -> NHWC (N,cout,OH,OW) of dtype: 3x3 stride-2 pad-1 conv with the [cout][32] matrix of
-    stem_pack_weights, no column tensor; optionally accumulates the BatchNorm batch statistics like conv_fwd."""
+    stem_pack_weights, no column tensor; optionally accumulates the BatchNorm batch statistics like conv_fwd, or (fused
+    inference, no statistics) applies act(y + bias) in the epilogue."""
     img = img if img.is_contiguous() else img.contiguous()
     n, c, h, w = img.shape
     assert c == 3
     oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = new_nhwc(n, cout, oh, ow, dtype, img.device)
-    lib.call("yolo_stem_conv_fwd", _p(img), _p(wp), _p(y), cout, _p(stats_acc), n, h, w, oh, ow, cout, dt(dtype), _stream(img))
+    lib.call("yolo_stem_conv_fwd", _p(img), _p(wp), _p(y), cout, _p(stats_acc), n, h, w, oh, ow, cout, _p(bias), act, dt(dtype),
+             _stream(img))
     return y
 
 
@@ -408,6 +410,18 @@ def dw_fwd(x, w9, stats_acc=None):
     lib.call("yolo_dwconv3x3_fwd", _p(x), ldx, _p(w9), _p(y), c, n, h, w, c, dt(x), _stream(x))
     if stats_acc is not None:
         bn_stats_acc(y, stats_acc)
+    return y
+
+
+def dw_fwd_act(x, w9, bias, act):
+    """act(depthwise3x3(x) + bias) in one launch (a fused model's depthwise blocks); None when the strip kernel does not take
+    the tensor (fp32, unaligned) -- the caller then runs dw_fwd + the element-wise pass."""
+    n, c, h, w, ldx = geom(x)
+    y = new_nhwc(n, c, h, w, x.dtype, x.device)
+    rc = lib.query("yolo_dwconv3x3_fwd_act", _p(x), ldx, _p(w9), _p(bias), _p(y), c, n, h, w, c, act, dt(x), _stream(x))
+    if rc == 1:
+        return None
+    lib.status(rc, "yolo_dwconv3x3_fwd_act")
     return y
 
 

@@ -112,9 +112,10 @@ long yolo_conv2d_wgrad_plan(int N, int H, int W, int Cin, int OH, int OW, int Co
 int yolo_stem_im2col(const void* img, int img_dtype, void* col, int col_dtype, int N, int H, int W, int OH, int OW, hipStream_t st);
 int yolo_stem_pack_weights(const void* w, int w_dtype, int Cout, void* out, int out_dtype, hipStream_t st);
 int yolo_stem_unpack_wgrad(const float* dw32, int Cout, void* dw, int dw_dtype, hipStream_t st);
-/* fused stem forward: conv straight from the NCHW fp32 image (no column tensor), BatchNorm statistics in the epilogue */
+/* fused stem forward: conv straight from the NCHW fp32 image (no column tensor), BatchNorm statistics in the epilogue;
+   bias (fp32 [Cout], optional) + act (0 / 1 = SiLU): the folded-BatchNorm inference form (model_blocks.py:36-37), without stats */
 int yolo_stem_conv_eligible(int img_dtype, int dtype, int Cout);
-int yolo_stem_conv_fwd(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW, int Cout, int dtype, hipStream_t st);
+int yolo_stem_conv_fwd(const float* img, const void* wp, void* y, int ldy, float* stats, int N, int H, int W, int OH, int OW, int Cout, const float* bias, int act, int dtype, hipStream_t st);
 /* stem weight gradient straight from the image (autograd's conv2d weight gradient of backbone.py:38; no column tensor):
    partial = fp32 scratch [yolo_stem_wgrad_slabs()][Cout][32]; dw = OIHW (Cout,3,3,3) of dw_dtype */
 int yolo_stem_wgrad_slabs();
@@ -122,6 +123,8 @@ int yolo_stem_wgrad(const float* img, const void* dy, int ldy, float* partial, v
 /* depthwise 3x3 (groups == channels: model_blocks.py:183, head.py:56,58) */
 int yolo_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int dtype, hipStream_t st);
 int yolo_dwconv3x3_fwd_stats(const void* x, int ldx, const float* w, void* y, int ldy, float* stats, int N, int H, int W, int C, int dtype, hipStream_t st);
+/* fused inference: y = act(dwconv(x) + bias), one launch (model_blocks.py:36-37 on a depthwise Conv); 1 = not taken, nothing launched */
+int yolo_dwconv3x3_fwd_act(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int H, int W, int C, int act, int dtype, hipStream_t st);
 int yolo_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int accumulate, int dtype, hipStream_t st);
 int yolo_dw_wgrad_nslab(int N, int H);
 int yolo_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* partial, int N, int H, int W, int C, int dtype, hipStream_t st);

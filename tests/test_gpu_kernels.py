@@ -268,6 +268,23 @@ def test_depthwise(dtype, c, h, w):
     check(o.dw_wgrad(dev(x), dev(dy)), emu.dw_wgrad(x, dy), torch.float32, "dw_wgrad", mult=4.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c,h,w", [(16, 12, 12), (80, 13, 21), (512, 20, 20), (2056, 3, 5)])
+def test_fused_inference_depthwise_bias_silu(dtype, c, h, w):
+    """yolo_dwconv3x3_fwd_act: act(depthwise(x) + bias) in the strip kernel's epilogue == depthwise, then bias + SiLU in fp32
+    on the unrounded sums; a channel count the strip kernel does not take (12) reports 'not taken'."""
+    o = ops()
+    x = nhwc(rnd(2, c, h, w, seed=24).to(dtype))
+    w9, bias = rnd(c, 9, seed=25, scale=0.3), rnd(c, seed=26, scale=0.5)
+    ref = torch.nn.functional.conv2d(x.float(), w9.view(c, 1, 3, 3), bias, 1, 1, groups=c)
+    for act in (1, 0):
+        got = o.dw_fwd_act(dev(x), w9.to(DEV), bias.to(DEV), act)
+        assert got is not None
+        check(got, torch.nn.functional.silu(ref) if act else ref, dtype, f"dw_fwd_act act={act}", mult=2.0)
+    x12 = nhwc(rnd(2, 12, 5, 6, seed=27).to(dtype))
+    assert o.dw_fwd_act(dev(x12), rnd(12, 9, seed=28).to(DEV), rnd(12, seed=29).to(DEV), 1) is None
+
+
 # ------------------------------------------------------------------------------------------ BN + act
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("c,act,pad", [(16, 1, 0), (24, 0, 8), (96, 1, 0), (6, 1, 0)])
@@ -409,6 +426,26 @@ def test_fused_inference_conv_bias_silu_residual(dtype, cin, cout, h, w, k, s):
             if r is not None:
                 want = want + r.float()
             check(got, want, dtype, f"conv_fwd_act act={act} res={r is not None}", mult=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cout,h,w", [(64, 1280, 1280), (32, 17, 23), (48, 9, 515)])
+def test_fused_inference_stem_bias_silu(dtype, cout, h, w):
+    """yolo_stem_conv_fwd with bias + act: the fused model's first block (3 -> C, 3x3 / 2; no MFMA conv kernel takes Cin = 3,
+    without this epilogue it ran on the scalar kernel: 4.9 of 10.6 ms of preset l @1280) == SiLU(conv(img) + b); with
+    statistics requested the combination is refused."""
+    o = ops()
+    n = 1 if h > 1000 else 2
+    img = rnd(n, 3, h, w, seed=84)
+    wt = rnd(cout, 3, 3, 3, seed=85, scale=0.2)
+    bias = rnd(cout, seed=86, scale=0.5)
+    wp = o.stem_pack_weights(wt.to(DEV), dtype)
+    ref = torch.nn.functional.conv2d(img.to(dtype).float(), wt.to(dtype).float(), bias, 2, 1)
+    for act in (1, 0):
+        got = o.stem_conv_fwd(img.to(DEV), wp, cout, dtype, None, bias.to(DEV), act)
+        check(got, torch.nn.functional.silu(ref) if act else ref, dtype, f"fused stem act={act}", mult=2.0)
+    with pytest.raises(Exception):
+        o.stem_conv_fwd(img.to(DEV), wp, cout, dtype, o.bn_acc_new(cout, DEV), bias.to(DEV), 1)
 
 
 # ------------------------------------------------------------------------------------------ loss

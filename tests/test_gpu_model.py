@@ -280,10 +280,17 @@ def test_fused_inference_equals_unfused_eval(precision):
     dt = getattr(torch, precision)
     img = torch.randn(2, 3, 320, 320, generator=torch.Generator().manual_seed(23))
     plain, fused = _model(seed=7, cfg=cfg).eval(), _model(seed=7, cfg=cfg).eval().fuse()
-    with torch.no_grad(), torch.autocast("cuda", dtype=dt):
-        p0 = plain(img.cuda())[0]
-        p1 = fused(img.cuda())[0]
-        p2 = fused(img.cuda())[0]                      # second call: the cached packed weights
+    from src.hipops import ops as hops
+    stem_calls, real_stem = [], hops.stem_conv_fwd
+    hops.stem_conv_fwd = lambda *a, **k: (stem_calls.append(len(a) > 6 and a[5] is not None and a[6] == 1), real_stem(*a, **k))[1]
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=dt):
+            p0 = plain(img.cuda())[0]
+            p1 = fused(img.cuda())[0]
+            p2 = fused(img.cuda())[0]                      # second call: the cached packed weights
+    finally:
+        hops.stem_conv_fwd = real_stem
+    assert stem_calls[-2:] == [True, True], "the fused model's stem must take the stem kernel with bias + SiLU in its epilogue"
     ps = ParamStore(7)
     with torch.no_grad():
         p_ref, _, _ = ob.model_forward(ps, img, cfg["width"], cfg["depth"], cfg["csp"], 80, training=False)
