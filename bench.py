@@ -346,6 +346,33 @@ def measure_inference(dev, preset="l", res=1280, batch=4, nc=80, reps=10):
                 forward_tflops=round(347.64 * batch / fwd, 1) if (preset, res) == ("l", 1280) else None)
 
 
+def measure_single_image(dev, preset, res=640, nc=80, reps=30):
+    """`Model.inference(image)` -- the reference's one-image entry point -- on a fused fp16 model: ms per call with the
+    forward + decode replayed as one hipGraph (the default, src/model/infer_graph.py) and launch by launch."""
+    from src.model.model_builder import Model
+    torch.manual_seed(0)
+    model = Model(**PRESETS[preset], num_classes=nc).to(dev).eval().fuse()
+    img = torch.randn(1, 3, res, res, device=dev)
+    out = {}
+    was = Model.graph_inference
+    try:
+        for name, flag in (("replayed_ms", True), ("eager_ms", False)):
+            Model.graph_inference = flag
+            with torch.autocast("cuda", dtype=torch.float16):
+                for _ in range(3):
+                    model.inference(img)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    model.inference(img)
+                torch.cuda.synchronize()
+            out[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+    finally:
+        Model.graph_inference = was
+    out.update(res=res, hip_graph=bool(model._infer_graphs is not None and model._infer_graphs.disabled is None))
+    return out
+
+
 def measure_nms(dev):
     """Class-aware NMS on BASELINE config 5's tensor (8 x 84 x 33600, fp16) on the device: ms per image."""
     from src.utils.model_utils import non_max_suppression
@@ -537,6 +564,7 @@ def main():
             extra["preset_l_640_bf16_16img"] = measure_preset("l", 16, args.res, nc, dev, steps=20, warmup=5)
             extra["nms_config5_fp16_8img"] = measure_nms(dev)
             extra["inference_l_1280_fp16_fused"] = measure_inference(dev)
+            extra["inference_one_image_fp16_fused"] = {p: measure_single_image(dev, p) for p in ("s", "l")}
             extra["preset_s_640_bf16_32img_deterministic_mode"] = measure_preset("s", args.batch, args.res, nc, dev, steps=10, warmup=3, deterministic=True)
             extra["preset_l_fsdp2_bf16_16img"] = measure_fsdp2("l", 16, args.res, nc, dev, steps=10, warmup=3)
             extra["preset_l_sharded_captured_bf16_16img"] = measure_sharded("l", 16, args.res, nc, dev, steps=20, warmup=5)

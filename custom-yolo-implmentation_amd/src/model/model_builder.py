@@ -10,6 +10,7 @@ from src.hipops import functions as F_
 from src.hipops import ops
 from src.model.backbone import Backbone
 from src.model.head import Head
+from src.model.infer_graph import InferenceGraphs
 from src.model.model_blocks import Conv
 from src.model.neck import Neck
 from src.utils.model_utils import fuse_conv, non_max_suppression
@@ -22,6 +23,9 @@ class Model(nn.Module):
     # TrainStepRunner's staged backward: a callable that receives the backbone's outputs and returns what the neck should
     # read instead (detached leaves), cutting the autograd graph at the backbone / neck boundary
     stage_cut = None
+    # inference() replays forward + decode as one hipGraph per input shape (src/model/infer_graph.py); False, or
+    # YOLO_INFER_GRAPH=0 in the environment, issues the launches one by one as forward() does
+    graph_inference = os.environ.get("YOLO_INFER_GRAPH", "1") == "1"
 
     def __init__(self, width: List[int], depth: List[int], csp: List[bool], num_classes: int):
         super().__init__()
@@ -36,6 +40,11 @@ class Model(nn.Module):
         for m in self.modules():                 # BatchNorm's num_batches_tracked: one multi-tensor add per
             if type(m) is Conv:                  # forward instead of one tiny kernel per layer
                 m._count_batches = False
+        self._infer_graphs = None
+
+    def _apply(self, fn, *args, **kwargs):       # .to() / .half() / .cuda(): new storages -- captured graphs point at the old
+        self._infer_graphs = None
+        return super()._apply(fn, *args, **kwargs)
 
     def forward(self, x):
         if not self.training:
@@ -78,6 +87,7 @@ class Model(nn.Module):
 
     def fuse(self):
         """Fold every Conv's BatchNorm into its conv (inference only), reference :52-58."""
+        self._infer_graphs = None
         for m in self.modules():
             if type(m) is Conv and hasattr(m, "norm"):
                 m.conv = fuse_conv(m.conv, m.norm)
@@ -92,6 +102,7 @@ class Model(nn.Module):
         # them (notebooks/04); keys are matched by their canonical names here
         from src.training.utils_train import canonical_state_dict
         self.load_state_dict(canonical_state_dict(state))
+        self._infer_graphs = None
         print(f"Weights loaded successfully from {weights_path}")
 
     def inference(self, image, conf_thres=0.25, iou_thres=0.45):
@@ -115,6 +126,12 @@ class Model(nn.Module):
             image = image.unsqueeze(0)
         image = image.to(next(self.parameters()).device)
         with torch.no_grad():
-            preds, anchors, strides = self.forward(image)
-            y = ops.head_decode(preds, anchors, strides, self.head.nc)
+            y = None
+            if self.graph_inference and image.is_cuda:
+                if self._infer_graphs is None:
+                    self._infer_graphs = InferenceGraphs()
+                y = self._infer_graphs.run(self, image)
+            if y is None:
+                preds, anchors, strides = self.forward(image)
+                y = ops.head_decode(preds, anchors, strides, self.head.nc)
             return non_max_suppression(y, conf_thres=conf_thres, iou_thres=iou_thres, nc=self.num_classes)

@@ -299,3 +299,52 @@ def test_fused_inference_equals_unfused_eval(precision):
     assert torch.equal(p1, p2)
     tol = 2e-2 if precision == "float16" else 8e-2
     assert e1r < tol and e1r < 2 * e0r + 1e-3
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_replayed_inference_equals_eager_inference(fused):
+    """Model.inference replays forward + decode as one hipGraph per input shape (src/model/infer_graph.py): detections
+    bit-identical to the launch-by-launch path on every image, a new shape captures a new graph, in-place weight updates
+    are seen (unfused: the kernels read the live parameters; a changed version counter re-captures), .half() drops the
+    graphs, and a training-mode or grad-enabled call never replays."""
+    from src.model.model_builder import Model
+    g = torch.Generator().manual_seed(31)
+    imgs = [torch.randn(1, 3, 320, 320, generator=g).cuda() for _ in range(3)] + [torch.randn(2, 3, 256, 384, generator=g).cuda()]
+    model = _model(seed=9, cfg=ob.PRESETS["s"]).eval()
+    with torch.no_grad():
+        for lvl in model.head.cls:                   # enough confident anchors for the NMS to have work
+            lvl[-1].weight.mul_(0.05)
+            lvl[-1].bias.copy_(torch.linspace(-2.0, 1.0, 80, device="cuda"))
+    if fused:
+        model.fuse()
+
+    def both(img, conf=0.05):
+        Model.graph_inference = False
+        try:
+            eager = model.inference(img, conf_thres=conf)
+        finally:
+            Model.graph_inference = True
+        return eager, model.inference(img, conf_thres=conf)
+
+    with torch.autocast("cuda", dtype=torch.float16):
+        for img in imgs + imgs[:1]:
+            eager, replayed = both(img)
+            assert len(eager) == len(replayed) == img.shape[0] and sum(e.shape[0] for e in eager) > 0
+            for e, r in zip(eager, replayed):
+                assert torch.equal(e, r)
+        graphs = model._infer_graphs
+        assert graphs is not None and graphs.disabled is None and len(graphs.entries) == 2
+        first = replayed = model.inference(imgs[0], conf_thres=0.05)
+        # in-place update of a weight: the next call must see it
+        with torch.no_grad():
+            w = model.head.box[0][-1].weight
+            w.mul_(1.5)
+        eager, replayed = both(imgs[0])
+        assert all(torch.equal(e, r) for e, r in zip(eager, replayed))
+        assert not all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(first, replayed)), "stale weights replayed"
+    model.half()
+    assert model._infer_graphs is None
+    eager, replayed = both(imgs[0].half())
+    assert all(torch.equal(e, r) for e, r in zip(eager, replayed))
+    with torch.enable_grad():
+        assert model._infer_graphs.run(model, imgs[0].half()) is None
