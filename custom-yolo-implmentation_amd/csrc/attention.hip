@@ -477,6 +477,8 @@ int attn_bwd_mfma(const T* qkv, int ldq, const T* d_o, int lddo, const T* d_vp, 
 
 // attention_fused.hip: flash-style MFMA kernels for dk = 32, dh = 64, <= 448 tokens (stash = row log-sum-exp, fp32)
 int attn_fused_ok(int T_, int dk, int dh, int dtype);
+int attn_fused_fwd_nograd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, int N, int T_, int heads, float scale,
+                          int dtype, hipStream_t st);
 int attn_fused_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, float* lse, int N, int T_, int heads, float scale,
                    int dtype, hipStream_t st);
 int attn_fused_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv,
@@ -528,6 +530,16 @@ int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv,
     if (rc) return rc;
     hipLaunchKernelGGL((k_attn_fwd<float>), grid, dim3(256), smem, st, a, (const float*)qkv, (float*)o, (float*)vp, (float*)stash);
     return YOLO_LAUNCH_CHECK();
+}
+
+// The same forward when no backward will follow (inference, no-grad): nothing is stashed and the fused kernels take any
+// sequence length (key-blocked online softmax beyond 448 tokens -- 1600 at 1280 x 1280).  Returns 1 when they do not take
+// the problem (fp32, other head shapes, YOLO_ATTN_FUSED=0): nothing was launched, the caller uses yolo_attn_fwd.
+int yolo_attn_fwd_nograd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, int N, int T_, int heads, int dk, int dh,
+                         float scale, int dtype, hipStream_t st) {
+    if (!dims_ok(dk, dh)) return YOLO_ERR_ARG;
+    if (dtype == YOLO_F32 || !attn_fused_ok(1, dk, dh, dtype) || T_ < 1) return 1;
+    return attn_fused_fwd_nograd(qkv, ldq, o, ldo, vp, ldv, N, T_, heads, scale, dtype, st);
 }
 
 // dqkv (N, T, heads*(2dk+dh)) fully written; d_vp may be null

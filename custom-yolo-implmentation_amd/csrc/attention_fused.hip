@@ -1,4 +1,5 @@
-// PSA attention core for 16-bit tensors with dk = 32, dh = 64 and up to 448 tokens (every preset at 640x640: 400 tokens),
+// PSA attention core for 16-bit tensors with dk = 32, dh = 64: training up to 448 tokens (every preset at 640x640: 400
+// tokens), forward-only passes at any length (k_attn_fwd_long below),
 // flash-style on the matrix cores: no score / probability / dP matrix ever reaches memory (the batched-GEMM route of
 // attention.hip writes and re-reads 85 MB of fp32 scores, 42 MB of probabilities and the same again for dP / dS per
 // step, in 14 launches; it remains for longer sequences and other head shapes).
@@ -178,7 +179,96 @@ __global__ __launch_bounds__(1024) void k_attn_fwd_fused(FDims a, const T* __res
             for (int r = 0; r < 4; ++r) v[r] = oacc[dt][r] * inv;
             store_pack<T, 4>(orow + dt * 16 + 4 * g, v);
         }
-        if (g == 0) lse[((long)n * a.heads + h) * a.T + qrow] = m + __logf(l);
+        if (g == 0 && lse != nullptr) lse[((long)n * a.heads + h) * a.T + qrow] = m + __logf(l);
+    }
+}
+
+// Forward without a backward stash for sequences beyond one LDS image (1280 x 1280 inputs: 1600 tokens; inference and
+// no-grad passes).  The keys are walked in blocks of 256 tokens -- K and V of one block in LDS -- with the running column
+// maximum and sum rescaled per block (online softmax); inside a block the two passes of k_attn_fwd_fused.  The batched-GEMM
+// route it replaces writes 41 MB of fp32 scores and 20 MB of probabilities per image of preset l and takes ~100 us per
+// PSABlock at 4 images.
+constexpr int LONG_NP = 8, LONG_ROWS = LONG_NP * 32;
+template <typename T>
+__global__ __launch_bounds__(1024) void k_attn_fwd_long(FDims a, const T* __restrict__ qkv, T* __restrict__ o, T* __restrict__ vp) {
+    typedef typename mm<T>::frag frag;
+    __shared__ __attribute__((aligned(16))) T Ks[LONG_ROWS * LDK];
+    __shared__ __attribute__((aligned(16))) T Vs[LONG_ROWS * LDV];
+    const int qb = (blockDim.x >> 6) * 16;
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * qb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, c4 = 4 * (i16 & 3);
+    const T* base = qkv + (long)n * a.T * a.ldq + h * CQ;
+    const int qrow = q0 + wave * 16 + i16;
+    const bool qok = qrow < a.T;
+    const frag bq = load_frag<T>(base + (long)(qok ? qrow : 0) * a.ldq + g * 8, true);
+    // v re-gathered to [token][head*dh] for the positional depthwise conv: this workgroup's tokens, straight from qkv
+    for (int idx = threadIdx.x; idx < qb * (DH / 8); idx += blockDim.x) {
+        const int r = idx / (DH / 8), ch = (idx - r * (DH / 8)) * 8;
+        if (q0 + r < a.T)
+            *reinterpret_cast<uint4*>(vp + ((long)n * a.T + q0 + r) * a.ldv + h * DH + ch) =
+                *reinterpret_cast<const uint4*>(base + (long)(q0 + r) * a.ldq + 2 * DK + ch);
+    }
+    float m = -INFINITY, l = 0.f;
+    f32x4 oacc[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < a.T; k0 += LONG_ROWS) {
+        __syncthreads();                                      // the previous block's fragment reads are done
+        stage_tokens<T, LDK>(Ks, base + (long)k0 * a.ldq, a.ldq, DK, DK, LONG_ROWS, a.T - k0);
+        stage_tokens<T, LDV>(Vs, base + (long)k0 * a.ldq, a.ldq, 2 * DK, DH, LONG_ROWS, a.T - k0);
+        __syncthreads();
+        const int left = a.T - k0;                            // valid keys in this block: >= 1
+        float mb = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * LONG_NP; ++t) {
+            const f32x4 st = mm<T>::mma(*reinterpret_cast<const frag*>(Ks + (16 * t + i16) * LDK + g * 8), bq, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * t + 4 * g + r < left) mb = fmaxf(mb, st[r] * a.scale);
+        }
+        const float mn = fmaxf(m, xmax(mb));                  // finite from the first block on
+        const float corr = __expf(m - mn);                    // first block: exp(-inf) = 0 on zero accumulators
+        m = mn;
+        l *= corr;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= corr;
+        __asm__ volatile("" ::: "memory");                    // pass 2 re-reads K instead of keeping 16 score tiles alive
+#pragma unroll
+        for (int u = 0; u < LONG_NP; ++u) {
+            float pv[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int t = 2 * u + half;
+                const f32x4 st = mm<T>::mma(*reinterpret_cast<const frag*>(Ks + (16 * t + i16) * LDK + g * 8), bq, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (16 * t + 4 * g + r < left) ? __expf(st[r] * a.scale - m) : 0.f;
+                    pv[half * 4 + r] = p;
+                    l += p;
+                }
+            }
+            const frag pb = pack_frag<T>(pv);
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; ++dt) {
+                const T* p = Vs + (32 * u + 4 * g + q) * LDV + dt * 16 + c4;
+                oacc[dt] = mm<T>::mma(tr_frag<T>(p, p + 16 * LDV), pb, oacc[dt]);
+            }
+        }
+    }
+    l = xsum(l);
+    const float inv = 1.f / l;
+    if (qok) {
+        T* orow = o + ((long)n * a.T + qrow) * a.ldo + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = oacc[dt][r] * inv;
+            store_pack<T, 4>(orow + dt * 16 + 4 * g, v);
+        }
     }
 }
 
@@ -433,6 +523,24 @@ int attn_fused_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv
         return YOLO_ERR_ARG;
     const FDims a{N, T_, heads, ldq, ldo, ldv, scale};
     return dtype == YOLO_BF16 ? fwd_t<bf16_t>(a, qkv, o, vp, lse, st) : fwd_t<f16_t>(a, qkv, o, vp, lse, st);
+}
+
+// forward only (no stash): any sequence length; the one-image kernel up to 448 tokens, the key-blocked one beyond
+int attn_fused_fwd_nograd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, int N, int T_, int heads, float scale,
+                          int dtype, hipStream_t st) {
+    if (T_ <= 448) return attn_fused_fwd(qkv, ldq, o, ldo, vp, ldv, nullptr, N, T_, heads, scale, dtype, st);
+    if (ldq % 8 || ldo % 4 || ldv % 8 || (reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(vp) & 15) ||
+        (reinterpret_cast<uintptr_t>(o) & 7))
+        return YOLO_ERR_ARG;
+    const FDims a{N, T_, heads, ldq, ldo, ldv, scale};
+    // 256 queries per workgroup; 128 when that leaves CUs without one (every workgroup stages all of K and V once)
+    const int waves = (long)N * heads * ((T_ + 255) / 256) >= 256 ? 16 : 8;
+    const dim3 grid((T_ + waves * 16 - 1) / (waves * 16), heads, N), block(64 * waves);
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((k_attn_fwd_long<bf16_t>), grid, block, 0, st, a, (const bf16_t*)qkv, (bf16_t*)o, (bf16_t*)vp);
+    else
+        hipLaunchKernelGGL((k_attn_fwd_long<f16_t>), grid, block, 0, st, a, (const f16_t*)qkv, (f16_t*)o, (f16_t*)vp);
+    return YOLO_LAUNCH_CHECK();
 }
 
 // Dws: fp32 [N][heads][T] scratch; dqkv fully written

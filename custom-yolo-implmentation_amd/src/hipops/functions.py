@@ -761,6 +761,10 @@ class AttentionCore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, heads, dk, dh, scale):
         qkv = _as_nhwc(qkv, qkv.dtype)
+        if not ctx.needs_input_grad[0] and qkv.is_cuda:       # inference / no-grad: nothing to keep, any sequence length
+            got = ops.attn_fwd_nograd(qkv, heads, dk, dh, scale)
+            if got is not None:
+                return got
         o, vp, lse = ops.attn_fwd(qkv, heads, dk, dh, scale)
         ctx.cfg = (heads, dk, dh, scale)
         ctx.save_for_backward(qkv, o, lse)

@@ -591,6 +591,20 @@ def attn_fwd(qkv, heads, dk, dh, scale):
     return o, vp, stash
 
 
+def attn_fwd_nograd(qkv, heads, dk, dh, scale):
+    """-> (o, vp) with nothing kept for a backward, or None when the fused kernels do not take the problem (fp32, other
+    head shapes): any sequence length, no score / probability matrix in memory."""
+    n, cq, h, w, ld = geom(qkv)
+    o = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
+    vp = new_nhwc(n, heads * dh, h, w, qkv.dtype, qkv.device)
+    rc = lib.query("yolo_attn_fwd_nograd", _p(qkv), ld, _p(o), heads * dh, _p(vp), heads * dh, n, h * w, heads, dk, dh, float(scale),
+                   dt(qkv), _stream(qkv))
+    if rc == 1:
+        return None
+    lib.status(rc, "yolo_attn_fwd_nograd")
+    return o, vp
+
+
 def attn_bwd(qkv, o, d_o, d_vp, stash, heads, dk, dh, scale):
     n, cq, h, w, ld = geom(qkv)
     t = h * w

@@ -163,6 +163,8 @@ size_t yolo_attn_workspace_bytes(int N, int T_, int heads, int dtype);
 size_t yolo_attn_stash_bytes_for(int N, int T, int heads, int dk, int dh, int dtype);
 size_t yolo_attn_workspace_bytes_for(int N, int T, int heads, int dk, int dh, int dtype);
 int yolo_attn_fwd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, void* stash, void* ws, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
+/* forward with no backward to follow (inference / no-grad): no stash, any sequence length; 1 = not taken, nothing launched */
+int yolo_attn_fwd_nograd(const void* qkv, int ldq, void* o, int ldo, void* vp, int ldv, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
 int yolo_attn_bwd(const void* qkv, int ldq, const void* o, int ldo, const void* d_o, int lddo, const void* d_vp, int lddv, const void* stash, void* ws, void* dqkv, int lddq, int N, int T_, int heads, int dk, int dh, float scale, int dtype, hipStream_t st);
 
 /* ---- YoloDFLQFLoss forward+gradient (losses.py:93-281) */

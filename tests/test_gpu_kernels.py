@@ -399,6 +399,30 @@ def test_attention(dtype, heads, dk, dh, h, w):
     check(dq0, emu.attn_bwd(qkv, o_ref, d_o, None, lse_ref, heads, dk, dh, scale), dtype, "attn dqkv (d_vp None)", mult=4.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("heads,h,w", [(2, 6, 6), (4, 20, 20), (2, 23, 23), (4, 40, 40), (1, 16, 16), (2, 16, 17), (1, 37, 29)])
+def test_attention_forward_without_stash_any_length(dtype, heads, h, w):
+    """yolo_attn_fwd_nograd (inference / no-grad): <= 448 tokens the one-image kernel without its log-sum-exp store, beyond
+    it the key-blocked online-softmax kernel -- 1600 tokens (preset l @1280: the batched-GEMM route before), exactly one and
+    two key blocks (256, 272), 1073 = a partial last block and a partial last query tile; scores with a spread that makes
+    the running maximum move between blocks; fp32 is not taken (None)."""
+    o = ops()
+    n, dk, dh = 2, 32, 64
+    qkv = rnd(n, heads * (2 * dk + dh), h, w, seed=53)
+    qkv[:, :2 * dk] *= 2.5                            # sharper softmax: per-block maxima differ by several units
+    qkv = nhwc(qkv.to(dtype))
+    scale = dk ** -0.5
+    got = o.attn_fwd_nograd(dev(qkv), heads, dk, dh, scale)
+    if dtype == torch.float32:
+        assert got is None
+        return
+    o_ref, v_ref, _ = emu.attn_fwd(qkv, heads, dk, dh, scale)
+    check(got[0], o_ref, dtype, "attn o (no stash)", mult=2.0)
+    assert torch.equal(got[1].cpu(), v_ref)
+    if h * w <= 448:                                  # the same kernel as the stashing forward: identical output
+        assert torch.equal(got[0], o.attn_fwd(dev(qkv), heads, dk, dh, scale)[0])
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,h,w,k,s", [(64, 128, 80, 80, 1, 1),      # k_conv_mfma (large-map 1x1)
                                              (256, 128, 20, 20, 1, 1),     # k_conv_ring (small-map 1x1)
