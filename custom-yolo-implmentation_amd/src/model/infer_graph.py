@@ -3,8 +3,9 @@ per input shape.
 
 A single 640 x 640 image is ~220 launches of 2 - 30 us: issued one by one the host is the bottleneck (preset s: 2.7 ms per
 image eager against 0.94 ms replayed, preset l: 4.5 against 1.9 -- tools/infer_bench.py).  The graph holds the static input,
-every intermediate and the decoded (N, 4 + nc, M) output in its own pool; a call copies the image in, replays, and hands the
-output to the class-aware NMS (which returns fresh tensors, so nothing a caller keeps aliases the pool).
+every intermediate, the decoded (N, 4 + nc, M) tensor and the class-aware NMS on it (its launches have fixed grids: the
+candidate capacity, not the candidate count) in its own pool; a call copies the image in, replays, reads the per-image
+counts (the one device -> host sync of non_max_suppression) and returns CLONED rows, so nothing a caller keeps aliases the pool.
 
 Validity: the unfused model's kernels read parameters and BatchNorm buffers where they live, so in-place updates
 (optimizer steps, load_state_dict) are seen by the next replay.  What a replay cannot follow is a change of STORAGE or of the
@@ -24,22 +25,33 @@ class InferenceGraphs:
     def __init__(self):
         self.entries = collections.OrderedDict()
         self.disabled = None              # reason, once a capture has failed: that model runs eagerly from then on
+        self.tensors = None
+        self.modules = None
 
-    @staticmethod
-    def _stamp(model):
-        v = 0
-        for t in model.parameters():
-            v += t._version
-        for t in model.buffers():
-            v += t._version
-        return v
+    def _stamp(self, model):
+        """Sum of the version counters of every parameter and buffer (walking the module tree costs ~0.8 ms on preset s, so
+        the tensor list is kept; whatever replaces tensors or modules -- _apply, fuse, load_weights -- drops this object)."""
+        if self.tensors is None:
+            self.tensors = list(model.parameters()) + list(model.buffers())
+        return sum(t._version for t in self.tensors)
 
-    def run(self, model, image):
-        """Decoded predictions (N, 4 + nc, M) for `image` (a device tensor), replayed; None = run eagerly."""
+    def all_eval(self, model):
+        """Whether every module is in eval mode already -- what `model.eval()` would establish, without its walk over the
+        module tree on every call (~0.8 ms on preset s; the module list is kept like the tensor list)."""
+        if self.modules is None:
+            self.modules = list(model.modules())
+        return not any(m.training for m in self.modules)
+
+    def run(self, model, image, conf_thres, iou_thres):
+        """Detections (list of (n, 6) tensors, as non_max_suppression returns them) for `image` (a device tensor), replayed;
+        None = run eagerly."""
         if self.disabled is not None or not image.is_cuda or model.training or torch.is_grad_enabled():
             return None
         amp = torch.is_autocast_enabled()
-        key = (tuple(image.shape), image.dtype, image.device.index, amp, torch.get_autocast_dtype("cuda") if amp else None)
+        if not (0 <= conf_thres <= 1 and 0 <= iou_thres <= 1):
+            return None                                       # non_max_suppression raises the reference's assertion
+        key = (tuple(image.shape), image.dtype, image.device.index, amp, torch.get_autocast_dtype("cuda") if amp else None,
+               float(conf_thres), float(iou_thres))
         stamp = self._stamp(model)
         ent = self.entries.get(key)
         if ent is not None and ent["stamp"] != stamp:
@@ -47,7 +59,7 @@ class InferenceGraphs:
             self.entries.clear()                              # weights changed: every graph may hold stale packed copies
         if ent is None:
             try:
-                ent = self._capture(model, image, amp)
+                ent = self._capture(model, image, amp, float(conf_thres), float(iou_thres))
             except Exception as e:                            # noqa: BLE001 -- a model that cannot be captured stays usable
                 self.disabled = f"{type(e).__name__}: {e}"
                 warnings.warn(f"inference graph capture failed ({self.disabled}); running eagerly", stacklevel=3)
@@ -59,15 +71,21 @@ class InferenceGraphs:
         self.entries.move_to_end(key)
         ent["x"].copy_(image)
         ent["graph"].replay()
-        return ent["y"]
+        rows, counts, status = ent["y"]
+        host = torch.cat((counts, status)).tolist()           # the one device -> host sync, as in non_max_suppression
+        if host[-1]:
+            raise RuntimeError("yolo_nms: more candidates than the kernel capacity; raise conf_thres")
+        rows = rows.clone()
+        return [rows[i, :host[i]] for i in range(image.shape[0])]
 
     @staticmethod
-    def _capture(model, image, amp):
+    def _capture(model, image, amp, conf_thres, iou_thres):
         nc = model.head.nc
 
         def fwd(x):
             preds, anchors, strides = model.forward(x)
-            return ops.head_decode(preds, anchors, strides, nc)
+            y = ops.head_decode(preds, anchors, strides, nc)
+            return ops.nms(y, model.num_classes, conf_thres, iou_thres, None, False, False, 300)
 
         x = image.clone()
         cur = torch.cuda.current_stream(image.device)

@@ -108,7 +108,13 @@ class Model(nn.Module):
     def inference(self, image, conf_thres=0.25, iou_thres=0.45):
         """Detections [x1,y1,x2,y2,conf,cls] per image; class scores are the raw logits, as in the
         reference (:115-139).  Decode (DFL expectation -> xywh -> *stride) is one fused kernel."""
-        self.eval()
+        graphs = None
+        if self.graph_inference:
+            if self._infer_graphs is None:
+                self._infer_graphs = InferenceGraphs()
+            graphs = self._infer_graphs
+        if graphs is None or not graphs.all_eval(self):
+            self.eval()
         if isinstance(image, str):
             from PIL import Image
             image = Image.open(image).convert("RGB")
@@ -126,12 +132,10 @@ class Model(nn.Module):
             image = image.unsqueeze(0)
         image = image.to(next(self.parameters()).device)
         with torch.no_grad():
-            y = None
-            if self.graph_inference and image.is_cuda:
-                if self._infer_graphs is None:
-                    self._infer_graphs = InferenceGraphs()
-                y = self._infer_graphs.run(self, image)
-            if y is None:
-                preds, anchors, strides = self.forward(image)
-                y = ops.head_decode(preds, anchors, strides, self.head.nc)
+            if graphs is not None and image.is_cuda:
+                dets = graphs.run(self, image, conf_thres, iou_thres)
+                if dets is not None:
+                    return dets
+            preds, anchors, strides = self.forward(image)
+            y = ops.head_decode(preds, anchors, strides, self.head.nc)
             return non_max_suppression(y, conf_thres=conf_thres, iou_thres=iou_thres, nc=self.num_classes)

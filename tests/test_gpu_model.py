@@ -347,4 +347,4 @@ def test_replayed_inference_equals_eager_inference(fused):
     eager, replayed = both(imgs[0].half())
     assert all(torch.equal(e, r) for e, r in zip(eager, replayed))
     with torch.enable_grad():
-        assert model._infer_graphs.run(model, imgs[0].half()) is None
+        assert model._infer_graphs.run(model, imgs[0].half(), 0.05, 0.45) is None
