@@ -41,9 +41,11 @@ class Model(nn.Module):
             if type(m) is Conv:                  # forward instead of one tiny kernel per layer
                 m._count_batches = False
         self._infer_graphs = None
+        self._bn_convs = None
 
     def _apply(self, fn, *args, **kwargs):       # .to() / .half() / .cuda(): new storages -- captured graphs point at the old
         self._infer_graphs = None
+        self._bn_convs = None
         return super()._apply(fn, *args, **kwargs)
 
     def forward(self, x):
@@ -52,7 +54,9 @@ class Model(nn.Module):
             # parameters without touching their version counters): evaluation always packs afresh
             ops.ACTIVE_PACK_PLAN = None
             return self.head(list(self.fpn(self.net(x))))
-        convs = [m for m in self.modules() if type(m) is Conv and hasattr(m, "norm")]
+        convs = self._bn_convs                   # (walking the module tree costs ~0.8 ms per eager step on preset s)
+        if convs is None:
+            convs = self._bn_convs = [m for m in self.modules() if type(m) is Conv and hasattr(m, "norm")]
         torch._foreach_add_([m.norm.num_batches_tracked for m in convs], 1)
         self._prepack(x, convs)
         # one zeroed pool for every layer's BatchNorm accumulators of this pass (a single memset)
@@ -88,6 +92,7 @@ class Model(nn.Module):
     def fuse(self):
         """Fold every Conv's BatchNorm into its conv (inference only), reference :52-58."""
         self._infer_graphs = None
+        self._bn_convs = None
         for m in self.modules():
             if type(m) is Conv and hasattr(m, "norm"):
                 m.conv = fuse_conv(m.conv, m.norm)
