@@ -75,11 +75,23 @@ def status(rc, name):
         raise RuntimeError(f"{name} failed with status {rc}")
 
 
+_fn = {}
+
+
+def _entry(name):
+    f = _fn.get(name)
+    if f is None:
+        f = _fn[name] = getattr(load(), name)
+    return f
+
+
 def call(name, *args):
     """Checked call of an int-returning entry point."""
-    status(getattr(load(), name)(*args), name)
+    rc = _entry(name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc}")
 
 
 def query(name, *args):
     """Unchecked call (size / capacity queries)."""
-    return getattr(load(), name)(*args)
+    return _entry(name)(*args)

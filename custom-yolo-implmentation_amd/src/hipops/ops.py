@@ -26,7 +26,13 @@ def _stream(t):
     if not t.is_cuda:
         raise RuntimeError("yolo_hip ops need tensors on the GPU: the product path has no CPU fallback "
                            "(the CPU oracle lives under oracle/ and is test infrastructure)")
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _raw_stream(t.device.index)
+
+
+# the current stream's handle without building a torch.cuda.Stream object per launch (4.7 us each, 2.5 ms of a 21.7 ms
+# launch-by-launch step of preset s: tools/host_profile.py)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or \
+    (lambda index: torch.cuda.current_stream(index).cuda_stream)
 
 
 def _p(t):
