@@ -75,12 +75,16 @@ class Model(nn.Module):
         """Pack every dense conv weight (forward + dgrad forms) with one launch instead of two per layer.
         Only for plain local parameters; sharded/wrapped parameters (FSDP) fall back to per-layer packing."""
         ops.ACTIVE_PACK_PLAN = None
-        if not getattr(self, "prepack", False):      # opt-in (TrainStepRunner): parameters must be plain, stable
-            return                                   # local tensors -- never under FSDP, whose buffers come and go
-        dense = [(m.conv.weight, m._k, m._s) for m in convs if not m._dw and m.conv.weight.shape[1] != 3]
-        dense += [(b[-1].weight, 1, 1) for br in (self.head.box, self.head.cls) for b in br]
-        if any(type(w.data) is not torch.Tensor or not w.is_cuda for w, _, _ in dense):
+        if getattr(self, "prepack", None) is False:  # (True: TrainStepRunner; unset: decided per pass from the weights)
             return
+        dense = [(m.conv.weight, m._k, m._s) for m in convs if not m._dw and m.conv.in_channels != 3]
+        dense += [(b[-1].weight, 1, 1) for br in (self.head.box, self.head.cls) for b in br]
+        # plain, resident local tensors only -- never what a sharding wrapper manages: FSDP2 holds DTensors until a group is
+        # unsharded, FSDP1's original parameters are views of a flat parameter whose storage is freed between uses
+        for w, _, _ in dense:
+            if type(w.data) is not torch.Tensor or not w.is_cuda or w.dim() != 4 or getattr(w, "_fsdp_flattened", False) or \
+                    w.untyped_storage().size() < w.numel() * w.element_size():
+                return
         T = F_.compute_dtype(x, dense[0][0])
         key = (T, tuple(w.data_ptr() for w, _, _ in dense))
         plan = getattr(self, "_pack_plan", None)
