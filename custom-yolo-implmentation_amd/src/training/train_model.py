@@ -52,8 +52,8 @@ def _make_scaler(precision, distributed_mode, device, rank):
 
 class CapturedTraining:
     """Training batches go through `TrainStepRunner`: the step captured once as hipGraphs on static image / target buffers
-    that every batch refills (12.5 instead of 18 ms per step on preset s, where the eager loop is bound by the host's
-    launch rate).  The default in ddp mode on ONE GPU (`train(captured_step=None)`); with more than one rank it is opt-in
+    that every batch refills (10.4 instead of 13.4 ms per step on preset s: issued launch by launch the step is bound by the
+    host -- tools/host_profile.py; 21.7 ms before round 3's cuts of the per-launch Python work).  The default in ddp mode on ONE GPU (`train(captured_step=None)`); with more than one rank it is opt-in
     (`captured_step=True` / config key `training.captured_step: true`) until a multi-GPU run has verified it on hardware --
     the default there is the reference's eager loop under torch's DistributedDataParallel reducer.  `captured_step=False`
     keeps the eager loop everywhere.
