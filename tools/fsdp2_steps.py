@@ -48,6 +48,22 @@ for i in range(40):
 for i, (f, b, o) in enumerate(ts):
     print(f"step {i:2d}: fwd {f*1e3:6.1f} bwd {b*1e3:6.1f} opt+sync {o*1e3:6.1f} ms", file=sys.stderr)
 print(f"garbage collector: {gc_t[1]} collections, {gc_t[0]*1e3:.1f} ms in 40 steps; objects tracked {len(gc.get_objects())}", file=sys.stderr)
+if os.environ.get("FSDP2_CPROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(10):
+        opt.zero_grad()
+        preds, a, s = model(img)
+        loss, ld = crit(preds, gts, a, s)
+        loss.backward()
+        opt.step()
+    pr.disable()
+    torch.cuda.synchronize()
+    import io
+    buf = io.StringIO()
+    pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(40)
+    print(buf.getvalue(), file=sys.stderr)
 st = torch.cuda.memory_stats()
 print({k: st[k] for k in ("num_alloc_retries", "num_device_alloc", "num_device_free", "reserved_bytes.all.peak")}, file=sys.stderr)
 dist.destroy_process_group()
