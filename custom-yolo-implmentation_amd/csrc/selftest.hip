@@ -36,7 +36,37 @@ __global__ void k_selftest_glds(const uint4* __restrict__ in, uint4* __restrict_
     __syncthreads();
     out[l] = T[l];
 }
+
+// `rounds` device-wide barriers among the launch's workgroups (arrival counter per round, relaxed agent-scope polling, one
+// acquire fence after; bounded spin: a workgroup that gives up sets *timed_out and leaves).  What a "conv epilogue -> grid
+// barrier -> normalise" kernel would pay per layer on top of its work: tools/grid_barrier_cost.py, DESIGN section 6.
+__global__ __launch_bounds__(256) void k_selftest_grid_barrier(unsigned* __restrict__ counters, int rounds, int* __restrict__ timed_out,
+                                                               float* __restrict__ sink) {
+    float acc = 0.f;
+    for (int r = 0; r < rounds; ++r) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counters + r, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(counters + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                if (++spins > (1 << 22)) { *timed_out = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        __syncthreads();
+        acc += (float)r;
+    }
+    if (sink != nullptr && acc < 0.f) sink[blockIdx.x] = acc;
+}
 }  // namespace
+
+// counters: `rounds` zeroed unsigned ints; blocks must all be resident at once (<= 8 per CU for this kernel)
+extern "C" int yolo_selftest_grid_barrier(void* counters, int blocks, int rounds, int* timed_out, hipStream_t st) {
+    if (blocks < 1 || blocks > 2048 || rounds < 0 || rounds > 64) return YOLO_ERR_ARG;
+    hipLaunchKernelGGL(k_selftest_grid_barrier, dim3(blocks), dim3(256), 0, st, (unsigned*)counters, rounds, timed_out, (float*)nullptr);
+    return YOLO_LAUNCH_CHECK();
+}
 
 extern "C" int yolo_selftest_glds(const void* in128x16, void* out64x16, hipStream_t st) {
     hipLaunchKernelGGL(k_selftest_glds, dim3(1), dim3(64), 0, st, (const uint4*)in128x16, (uint4*)out64x16);

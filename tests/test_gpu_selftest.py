@@ -39,3 +39,17 @@ def test_lds_dma_lane_layout_and_out_of_range_lanes():
     kind = "zeros" if bool((oob == 0).all()) else "untouched" if bool((oob == -1431655766).all()) else "other"
     print("\\n[selftest] LDS-DMA out-of-range lanes leave:", kind, oob[0].tolist())
     assert kind in ("zeros", "untouched")
+
+
+def test_grid_barrier_completes_among_resident_workgroups():
+    """yolo_selftest_grid_barrier (the measurement kernel behind DESIGN section 6's refutation of a one-launch conv +
+    BatchNorm): every workgroup passes every round, nobody gives up, the arrival counters end at the workgroup count."""
+    import torch
+    from src.hipops import lib
+    blocks, rounds = 256, 3
+    counters = torch.zeros(rounds, dtype=torch.int32, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lib.call("yolo_selftest_grid_barrier", counters.data_ptr(), blocks, rounds, flag.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and counters.tolist() == [blocks] * rounds
