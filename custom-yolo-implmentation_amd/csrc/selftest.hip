@@ -40,15 +40,27 @@ __global__ void k_selftest_glds(const uint4* __restrict__ in, uint4* __restrict_
 // `rounds` device-wide barriers among the launch's workgroups (arrival counter per round, relaxed agent-scope polling, one
 // acquire fence after; bounded spin: a workgroup that gives up sets *timed_out and leaves).  What a "conv epilogue -> grid
 // barrier -> normalise" kernel would pay per layer on top of its work: tools/grid_barrier_cost.py, DESIGN section 6.
+template <bool TREE>
 __global__ __launch_bounds__(256) void k_selftest_grid_barrier(unsigned* __restrict__ counters, int rounds, int* __restrict__ timed_out,
                                                                float* __restrict__ sink) {
+    // TREE: 16 group counters (workgroup index mod 16) whose last arriver adds to the round's top counter -- arrivals no longer
+    // serialise on one address; everybody polls the top counter for 16.  Layout per round: [top][16 groups].
     float acc = 0.f;
+    const unsigned grp = blockIdx.x & 15u, in_grp = (gridDim.x - grp + 15u) / 16u;
     for (int r = 0; r < rounds; ++r) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(counters + r, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* top = counters + (TREE ? r * 17 : r);
+            unsigned want = gridDim.x;
+            if (TREE) {
+                want = gridDim.x < 16u ? gridDim.x : 16u;
+                const unsigned prev = __hip_atomic_fetch_add(top + 1 + grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (prev + 1u == in_grp) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
             int spins = 0;
-            while (__hip_atomic_load(counters + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 if (++spins > (1 << 22)) { *timed_out = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -61,10 +73,14 @@ __global__ __launch_bounds__(256) void k_selftest_grid_barrier(unsigned* __restr
 }
 }  // namespace
 
-// counters: `rounds` zeroed unsigned ints; blocks must all be resident at once (<= 8 per CU for this kernel)
-extern "C" int yolo_selftest_grid_barrier(void* counters, int blocks, int rounds, int* timed_out, hipStream_t st) {
+// counters: zeroed unsigned ints, `rounds` of them (tree 0: one arrival counter per round) or 17 * rounds (tree 1: a top
+// counter + 16 group counters per round); blocks must all be resident at once (<= 8 per CU for this kernel)
+extern "C" int yolo_selftest_grid_barrier(void* counters, int blocks, int rounds, int tree, int* timed_out, hipStream_t st) {
     if (blocks < 1 || blocks > 2048 || rounds < 0 || rounds > 64) return YOLO_ERR_ARG;
-    hipLaunchKernelGGL(k_selftest_grid_barrier, dim3(blocks), dim3(256), 0, st, (unsigned*)counters, rounds, timed_out, (float*)nullptr);
+    if (tree)
+        hipLaunchKernelGGL(k_selftest_grid_barrier<true>, dim3(blocks), dim3(256), 0, st, (unsigned*)counters, rounds, timed_out, (float*)nullptr);
+    else
+        hipLaunchKernelGGL(k_selftest_grid_barrier<false>, dim3(blocks), dim3(256), 0, st, (unsigned*)counters, rounds, timed_out, (float*)nullptr);
     return YOLO_LAUNCH_CHECK();
 }
 

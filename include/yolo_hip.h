@@ -205,7 +205,7 @@ int yolo_image_prep(const void* src, const void* table_dev, int N, int S, int ji
 int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st);
 int yolo_selftest_glds(const void* in128x16, void* out64x16, hipStream_t st);
 /* `rounds` device-wide barriers among `blocks` resident workgroups (bounded spin; *timed_out set if one gave up): the per-layer price of a one-launch conv + BatchNorm */
-int yolo_selftest_grid_barrier(void* counters, int blocks, int rounds, int* timed_out, hipStream_t st);
+int yolo_selftest_grid_barrier(void* counters, int blocks, int rounds, int tree, int* timed_out, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -41,15 +41,23 @@ def test_lds_dma_lane_layout_and_out_of_range_lanes():
     assert kind in ("zeros", "untouched")
 
 
-def test_grid_barrier_completes_among_resident_workgroups():
+@pytest.mark.parametrize("tree", [0, 1])
+def test_grid_barrier_completes_among_resident_workgroups(tree):
     """yolo_selftest_grid_barrier (the measurement kernel behind DESIGN section 6's refutation of a one-launch conv +
-    BatchNorm): every workgroup passes every round, nobody gives up, the arrival counters end at the workgroup count."""
+    BatchNorm), flat and two-level: every workgroup passes every round, nobody gives up, the arrival counters end at the
+    workgroup count (top counters of the two-level form: at 16)."""
     import torch
     from src.hipops import lib
-    blocks, rounds = 256, 3
-    counters = torch.zeros(rounds, dtype=torch.int32, device="cuda")
+    blocks, rounds = 250, 3
+    per = 17 if tree else 1
+    counters = torch.zeros(rounds * per, dtype=torch.int32, device="cuda")
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    lib.call("yolo_selftest_grid_barrier", counters.data_ptr(), blocks, rounds, flag.data_ptr(),
+    lib.call("yolo_selftest_grid_barrier", counters.data_ptr(), blocks, rounds, tree, flag.data_ptr(),
              torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert int(flag.item()) == 0 and counters.tolist() == [blocks] * rounds
+    assert int(flag.item()) == 0
+    c = counters.view(rounds, per)
+    if tree:
+        assert c[:, 0].tolist() == [16] * rounds and c[:, 1:].sum(1).tolist() == [blocks] * rounds
+    else:
+        assert c[:, 0].tolist() == [blocks] * rounds

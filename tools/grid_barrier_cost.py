@@ -15,13 +15,14 @@ dev = "cuda"
 flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
 
-def measure(blocks, rounds):
-    counters = torch.zeros(REP * max(rounds, 1), dtype=torch.int32, device=dev)
+def measure(blocks, rounds, tree):
+    per = (17 if tree else 1) * max(rounds, 1)
+    counters = torch.zeros(REP * per, dtype=torch.int32, device=dev)
 
     def body():
         ops.zero_(counters)
         for i in range(REP):
-            lib.call("yolo_selftest_grid_barrier", counters.data_ptr() + 4 * i * max(rounds, 1), blocks, rounds, flag.data_ptr(),
+            lib.call("yolo_selftest_grid_barrier", counters.data_ptr() + 4 * i * per, blocks, rounds, tree, flag.data_ptr(),
                      torch.cuda.current_stream().cuda_stream)
     body(); torch.cuda.synchronize()
     s = torch.cuda.Stream()
@@ -44,7 +45,9 @@ def measure(blocks, rounds):
     return best
 
 
-for blocks in (64, 128, 256, 512, 1024):
-    t = [measure(blocks, r) for r in (0, 1, 2, 4)]
-    print(f"{blocks:5d} workgroups: launch alone {t[0]:6.2f} us; + 1 barrier {t[1]:6.2f} (+{t[1] - t[0]:.2f}); + 2 {t[2]:6.2f}; "
-          f"+ 4 {t[3]:6.2f} -> {(t[3] - t[0]) / 4:.2f} us per barrier; timed out: {int(flag.item())}", flush=True)
+for tree in (0, 1):
+    print("one arrival counter per barrier" if not tree else "16 group counters + a top counter per barrier (arrivals spread over 16 addresses)")
+    for blocks in (64, 128, 256, 512, 1024):
+        t = [measure(blocks, r, tree) for r in (0, 1, 2, 4)]
+        print(f"{blocks:5d} workgroups: launch alone {t[0]:6.2f} us; + 1 barrier {t[1]:6.2f} (+{t[1] - t[0]:.2f}); + 2 {t[2]:6.2f}; "
+              f"+ 4 {t[3]:6.2f} -> {(t[3] - t[0]) / 4:.2f} us per barrier; timed out: {int(flag.item())}", flush=True)
