@@ -5,7 +5,7 @@
 #include "common.h"
 #include "conv_geom.h"
 
-int conv_wide_flag();            // conv_mfma.hip: 16-byte epilogue stores on (default) / off (YOLO_CONV_WIDE=0, yolo_conv_wide_set)
+int conv_wide_flag();            // conv_mfma.hip: 16-byte epilogue stores: 2 (default) exchange by v_permlane16_swap, 1 by ds_bpermute, 0 off (YOLO_CONV_WIDE, yolo_conv_wide_set)
 
 namespace {
 
@@ -90,6 +90,14 @@ __device__ __forceinline__ void fused_epilogue(float (&v)[4], int act, const voi
     }
 }
 
+// value of lane ^ 16 (gfx950's v_permlane16_swap_b32 swaps the odd 16-lane rows of its first operand with the even rows of
+// its second: with both operands = v, the first result holds v[lane - 16] in the odd rows, the second v[lane + 16] in the even
+// rows; tests/test_gpu_selftest.py pins the mapping)
+__device__ __forceinline__ unsigned swap_rows16(unsigned v, bool odd_row) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return odd_row ? r[0] : r[1];
+}
+
 // Epilogue of one output pixel: the WN 16-channel blocks of accumulator row `a` (lane: channels cq .. cq+3 of every block,
 // pixel = the lane's fr) -> bias, inference act / residual, accumulate sources, store.  Shared by the five MFMA conv kernels.
 // 16-byte stores where the destination allows it (base 16-byte aligned, row stride a multiple of 8 channels, G::wide): lanes
@@ -134,8 +142,13 @@ __device__ __forceinline__ void store_pixel_blocks(const G& g, const f32x4 (&a)[
             const uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
             const uint2 send = odd ? ua : ub;                      // what the partner keeps
             uint2 recv;
-            recv.x = __shfl_xor(send.x, 16, 64);
-            recv.y = __shfl_xor(send.y, 16, 64);
+            if (g.wide == 2) {                                     // v_permlane16_swap: a VALU exchange of 16-lane rows, no LDS op
+                recv.x = swap_rows16(send.x, odd);
+                recv.y = swap_rows16(send.y, odd);
+            } else {
+                recv.x = __shfl_xor(send.x, 16, 64);
+                recv.y = __shfl_xor(send.y, 16, 64);
+            }
             // even lane: block j, channels cq .. cq+7 = own | partner's; odd lane: block j+1, channels cq-4 .. cq+3
             const uint4 out = odd ? make_uint4(recv.x, recv.y, ub.x, ub.y) : make_uint4(ua.x, ua.y, recv.x, recv.y);
             const int c8 = cbase + (odd ? j + 1 : j) * 16 + (odd ? cq - 4 : cq);

@@ -487,12 +487,13 @@ extern "C" int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma, int 
 }
 
 static int& wide_state() {
-    static int v = [] { const char* e = getenv("YOLO_CONV_WIDE"); return e ? atoi(e) : 1; }();
+    static int v = [] { const char* e = getenv("YOLO_CONV_WIDE"); const int m = e ? atoi(e) : 2; return m < 0 ? 0 : m > 2 ? 2 : m; }();
     return v;
 }
 int conv_wide_flag() { return wide_state(); }
-// test / A-B override of the 16-byte epilogue stores (store_pixel_blocks): 1 on, 0 off
-extern "C" int yolo_conv_wide_set(int on) { wide_state() = on ? 1 : 0; return YOLO_OK; }
+// test / A-B override of the 16-byte epilogue stores (store_pixel_blocks): 0 off, 1 exchange through ds_bpermute, 2 exchange
+// through v_permlane16_swap
+extern "C" int yolo_conv_wide_set(int on) { wide_state() = on < 0 ? 0 : on > 2 ? 2 : on; return YOLO_OK; }
 
 int mfma_conv_eligible(const ConvGeom& g, int dtype, const void* src, const void* wm, const void* dst) {
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return 0;

@@ -24,7 +24,13 @@ __device__ __forceinline__ void rows_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
-template <int N> __device__ __forceinline__ void rows_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// The counted wait in front of a step's barrier ALSO waits for this wave's own LDS reads (lgkmcnt(0)): the barrier declares the
+// stage read in the previous step free, and hipcc software-pipelines fragment reads across a raw s_barrier (the reads are issued
+// before it, their s_waitcnt lgkmcnt comes after it).  A refill that has to fetch from memory arrives long after such a read has
+// executed; the zero-size-descriptor pieces issued "past the end of K" fetch nothing and can land first -- the read then returns
+// zeros: one (chunk, tap) product missing from a whole workgroup tile, sporadically (found in k_dgrad2_patch, round 3: DESIGN
+// section 6; tools/dbg_up2.py).
+template <int N> __device__ __forceinline__ void rows_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory"); }
 
 template <typename T, int W, int WGM, int NWAVE, int WN, int NST, bool ACC>
 __global__ __launch_bounds__(64 * NWAVE) void k_conv_rows(GeomDev g, const T* __restrict__ src, const T* __restrict__ wm,

@@ -39,7 +39,13 @@ __device__ __forceinline__ void up2_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds_
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
-template <int N> __device__ __forceinline__ void up2_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// The counted wait in front of a step's barrier ALSO waits for this wave's own LDS reads (lgkmcnt(0)): the barrier declares the
+// stage read in the previous step free, and hipcc software-pipelines fragment reads across a raw s_barrier (the reads are issued
+// before it, their s_waitcnt lgkmcnt comes after it).  A refill that has to fetch from memory arrives long after such a read has
+// executed; the zero-size-descriptor pieces issued "past the end of K" fetch nothing and can land first -- the read then returns
+// zeros: one (chunk, tap) product missing from a whole workgroup tile, sporadically (found in k_dgrad2_patch, round 3: DESIGN
+// section 6; tools/dbg_up2.py).
+template <int N> __device__ __forceinline__ void up2_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory"); }
 
 template <typename T, int TH, int BN, int WM, int NST, bool ACC>
 __global__ __launch_bounds__((TH / WM) * (BN / 32) * 64) __attribute__((amdgpu_waves_per_eu(8 / WM, 8 / WM))) void k_dgrad2_patch(
@@ -261,14 +267,9 @@ int up2_conv_launch(const ConvGeom* gs, int variant, const long* wm_off, long wm
     d.N = g.N; d.Hs = g.Hs; d.Ws = g.Ws; d.Cs = g.Cs; d.lds = g.lds; d.Hd = g.Hd; d.Wd = g.Wd; d.Cd = g.Cd; d.ldd = g.ldd;
     for (int c = 0; c < 4; ++c) { d.wm_off[c] = (int)wm_off[c]; d.Kpad[c] = gs[c].Kpad; }
     d.wm_elems = (int)wm_elems;
-    // 8-byte stores here.  With the 16-byte exchange path this kernel returned wrong values for parity class (1,1) -- always that
-    // class, whichever order the classes are stored in -- in a few waves of a 32-image launch (1-6 images of 32 per run, never at
-    // 4 images; the same binary with the path switched off at run time is exact over 36 all-image runs, also beside a second
-    // stream).  At a wrong pixel 2-43 of the 128 channels are off by 0.1-0.5 (values ~1): the size of ONE missing (chunk, tap)
-    // product, i.e. class (1,1)'s accumulators as the epilogue reads them.  128 s_nop or a workgroup barrier in front of the
-    // epilogue change nothing; storing that class once more through the 8-byte path right after makes it WORSE.  Unexplained
-    // (tools/dbg_up2.py, round 3); the exchange path stays off for this kernel.
-    d.wide = 0; d.act = 0; d.res = nullptr; d.ldr = 0; d.acc2 = nullptr; d.ld2 = 0;
+    // (Round 3: with the 16-byte exchange path this kernel returned a whole workgroup tile of parity class (1,1) short of one
+    // (chunk, tap) product in a few launches of a hundred.  Not the stores: the counted waits of the ring, see up2_wait.)
+    d.wide = conv_wide_flag(); d.act = 0; d.res = nullptr; d.ldr = 0; d.acc2 = nullptr; d.ld2 = 0;
     if (g.N * g.Hs * g.Ws == 0) return YOLO_OK;
 #define UP2_T(T_)                                                                                       \
     return variant == 16 ? launch_up2<T_, 16, 32, 4, 3>(d, src, wm, dst, accumulate, st)                \

@@ -204,6 +204,13 @@ int yolo_image_prep(const void* src, const void* table_dev, int N, int S, int ji
 /* ---- hardware self-tests (instruction semantics the tiled kernels assume; tests/test_gpu_selftest.py; no reference counterpart: model_blocks.py:1) */
 int yolo_selftest_tr16(const void* tile_in, void* out, hipStream_t st);
 int yolo_selftest_glds(const void* in128x16, void* out64x16, hipStream_t st);
+/* do cross-lane exchanges of one workgroup (spam 1 ds_bpermute, 2 v_permlane16_swap, 3 ds traffic, 0 VALU) disturb another workgroup's LDS-DMA on the same CU? */
+int yolo_selftest_dma_vs_xlane(const void* pattern4k, int blocks, int iters, int spam, void* errors, void* sink, hipStream_t st);
+/* do LDS-DMA transfers retire in issue order on vmcnt when a younger one has nothing to fetch (kind 1 zero-size descriptor, 2 out-of-range offset, 0 real)? */
+int yolo_selftest_dma_order(const void* src, long src_bytes, int blocks, int kind, void* errors2, hipStream_t st);
+/* the three-slot LDS-DMA ring (counted vmcnt, raw barrier) in even workgroups beside cross-lane traffic in odd ones: mismatching dwords */
+int yolo_selftest_ring_vs_xlane(const void* src, int steps, int blocks, int spam, void* errors, void* sink, hipStream_t st);
+int yolo_selftest_permlane16(const void* in64, void* out128, hipStream_t st);
 /* `rounds` device-wide barriers among `blocks` resident workgroups (bounded spin; *timed_out set if one gave up): the per-layer price of a one-launch conv + BatchNorm */
 int yolo_selftest_grid_barrier(void* counters, int blocks, int rounds, int tree, int* timed_out, hipStream_t st);
 

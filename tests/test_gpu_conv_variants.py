@@ -39,7 +39,7 @@ def _reset_tuning():
     lib().call("yolo_conv_tune_set", 0, -1, -1, -1, -1, 0, 0, 0)
     lib().call("yolo_wgrad_tune_set", 0, 0, 0, 0)
     lib().call("yolo_wgrad_tune_pf", 0)
-    lib().call("yolo_conv_wide_set", 1)
+    lib().call("yolo_conv_wide_set", 2)
 
 
 def rnd(shape, seed, scale=1.0, dtype=None):
@@ -334,11 +334,12 @@ def test_config2_forward_and_dgrad_calls_elementwise(config2_calls):
 
 
 def test_config2_wide_and_narrow_epilogue_stores_are_bit_identical_on_every_image(config2_calls):
-    """The 16-byte epilogue (store_pixel_blocks: a lane-pair exchange, then one 16-byte store) against the 8-byte form over the
-    WHOLE output of every distinct forward / data-gradient call of preset s @640 at 32 images -- same values, only the store
-    instructions differ, so the two must be bit-identical on all 32 images, accumulate forms included.  (The element-wise tests
-    compare five images per call against the CPU reference; the stride-2 patch kernel was found wrong in a few workgroups of
-    images they do not look at, and keeps the 8-byte form: a mismatch here names the kernel family to switch back.)"""
+    """The 16-byte epilogue (store_pixel_blocks: a lane-pair exchange -- by v_permlane16_swap, the default, or by ds_bpermute --
+    then one 16-byte store) against the 8-byte form over the WHOLE output of every distinct forward / data-gradient call of
+    preset s @640 at 32 images: same values, only the exchange and store instructions differ, so the three must be
+    bit-identical on all 32 images, accumulate forms included.  (The element-wise tests compare five images per call against
+    the CPU reference.  This all-image test is what found the ring race of round 3 -- a whole workgroup tile of the stride-2
+    patch kernel short of one product in images those tests do not look at: DESIGN section 6.)"""
     o, q = ops(), lib().query
     failures, plans = [], {}
     cases = [("fwd",) + c[:9] + (False,) for c in sorted(config2_calls["fwd"])] + [("dgrad",) + c for c in sorted(config2_calls["dgrad"])]
@@ -361,18 +362,19 @@ def test_config2_wide_and_narrow_epilogue_stores_are_bit_identical_on_every_imag
             run = lambda out: o.conv_dgrad(src, wb, cin, h, w, k, s, acc_into=out if acc else None) if acc else _dgrad_into(o, src, wb, cin, h, w, k, s, out)
             shape, ld_out = (n, cin, h, w), ld_a
         outs = []
-        for wide in (1, 0):
+        for wide in (2, 1, 0):              # exchange by v_permlane16_swap (default) / by ds_bpermute / 8-byte stores
             lib().call("yolo_conv_wide_set", wide)
             base = rnd(shape, 5)
             dst, _, _ = on_dev(base, ld_out)
             r = run(dst)
             outs.append((r if r is not None else dst).clone())
-        lib().call("yolo_conv_wide_set", 1)
+        lib().call("yolo_conv_wide_set", 2)
         plans[plan // 1000] = plans.get(plan // 1000, 0) + 1
-        if not torch.equal(outs[0], outs[1]):
-            bad = (outs[0] != outs[1])
-            imgs = bad.flatten(1).any(1).nonzero().flatten().tolist()
-            failures.append(f"{kind} {(n, cin, cout, h, w, k, s)} acc={acc} plan {plan}: {int(bad.sum())} elements differ, images {imgs[:8]}")
+        for name, other in (("permlane vs 8-byte", outs[2]), ("permlane vs bpermute", outs[1])):
+            if not torch.equal(outs[0], other):
+                bad = (outs[0] != other)
+                imgs = bad.flatten(1).any(1).nonzero().flatten().tolist()
+                failures.append(f"{kind} {(n, cin, cout, h, w, k, s)} acc={acc} plan {plan} ({name}): {int(bad.sum())} elements differ, images {imgs[:8]}")
     print(f"\n[wide vs narrow stores] {len(seen)} calls, kernel kinds (plan // 1000 -> count): {plans}")
     assert not failures, "\n".join(failures)
 

@@ -61,3 +61,17 @@ def test_grid_barrier_completes_among_resident_workgroups(tree):
         assert c[:, 0].tolist() == [16] * rounds and c[:, 1:].sum(1).tolist() == [blocks] * rounds
     else:
         assert c[:, 0].tolist() == [blocks] * rounds
+
+
+def test_permlane16_swap_row_mapping():
+    """v_permlane16_swap_b32 with both operands equal: the lane ^ 16 exchange of store_pixel_blocks (conv_dev.h) without an
+    LDS operation -- first result = v[lane - 16] in the odd 16-lane rows, second = v[lane + 16] in the even rows."""
+    from src.hipops import lib
+    v = (torch.arange(64, dtype=torch.int32) * 7 + 3).cuda()
+    out = torch.zeros(128, dtype=torch.int32, device="cuda")
+    lib.call("yolo_selftest_permlane16", v.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    r = out.cpu().view(64, 2)
+    vc = v.cpu()
+    for lane in range(64):
+        odd = (lane >> 4) & 1
+        assert int(r[lane, 0 if odd else 1]) == int(vc[lane ^ 16]), (lane, r[lane].tolist())
