@@ -101,7 +101,7 @@ int yolo_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldy, float* ws
 int yolo_conv_tune_set(int bn, int tap_inner, int halo, int dma, int ring, int bm, int nst, int bk);
 int yolo_wgrad_tune_set(int to, int ti, int blocks, int min_per);
 int yolo_wgrad_tune_pf(int pf);
-int yolo_conv_wide_set(int on);
+int yolo_conv_wide_set(int on);   /* conv epilogue stores: 2 = 16-byte, lane-pair exchange by v_permlane16_swap (default); 1 = by ds_bpermute; 0 = 8-byte */
 /* which kernel a forward (mode 0) / data-gradient (mode 1, parity class cls for stride 2) launch of this shape takes:
    kind * 1000 + width, kind 1 = gather MFMA kernel (width = channel tile 32/64/128), 2 = halo MFMA kernel (width = variant 1..4),
    3 = pipelined ring kernel (width = channel tile, + 500 for 64-pixel tiles), 0 = VALU kernels */
