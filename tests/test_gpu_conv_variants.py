@@ -379,6 +379,33 @@ def test_config2_wide_and_narrow_epilogue_stores_are_bit_identical_on_every_imag
     assert not failures, "\n".join(failures)
 
 
+@pytest.mark.parametrize("wide", [1, 2, 0])
+def test_stride2_patch_kernel_repeats_bit_for_bit_on_every_image(wide):
+    """Regression for round 3's ring race (conv_up2.hip: up2_wait): the 128 -> 128 3x3 / 2 data gradient @160x160 at 32 images,
+    the launch in which whole workgroup tiles used to come out one product short in a few runs of a hundred (with the
+    ds_bpermute epilogue, wide = 1, within a dozen).  Twelve launches, every image, each compared bit for bit with the first;
+    the first against the 8-byte-store form."""
+    o = ops()
+    n, c, h, w = 32, 128, 160, 160
+    dy, _, _ = on_dev(rnd((n, c, h // 2, w // 2), 61))
+    wt = rnd((c, c, 3, 3), 62, (c * 9) ** -0.5).float().to(DEV)
+    wb = o.pack_weights(wt, 3, 2, 1, BF)
+    lib().call("yolo_conv_wide_set", 0)
+    ref = o.conv_dgrad(dy, wb, c, h, w, 3, 2).clone()
+    lib().call("yolo_conv_wide_set", wide)
+    side = torch.cuda.Stream()
+    a, b = torch.empty(32 << 20, device=DEV), torch.empty(32 << 20, device=DEV)
+    for rep in range(12):
+        with torch.cuda.stream(side):           # a bandwidth-hungry neighbour, as in the training step
+            b.copy_(a)
+        got = o.conv_dgrad(dy, wb, c, h, w, 3, 2)
+        if not torch.equal(got, ref):
+            bad = got != ref
+            imgs = bad.flatten(1).any(1).nonzero().flatten().tolist()
+            raise AssertionError(f"launch {rep}: {int(bad.sum())} elements differ from the 8-byte form, images {imgs}")
+    torch.cuda.synchronize()
+
+
 def _dgrad_into(o, src, wb, cin, h, w, k, s, out):
     """plain (non-accumulating) data gradient; the result tensor is the kernel's own allocation"""
     return o.conv_dgrad(src, wb, cin, h, w, k, s)
