@@ -253,7 +253,8 @@ int up2_conv_variant(const ConvGeom* gs, int dtype) {
             if (q.dh[t] != t / nw || q.dw[t] != t % nw) return 0;
     }
     // measured on every stride-2 layer of the step (tools/up2_bench.py, 32 images, ring -> here): 32->64 @320x320 157 -> 98 us,
-    // 128->128 @160 145 -> 107, 256->256 @80 114 -> 88, 128->128 @80 50 -> 35, 256->256 @40 40 -> 35, 256->512 @40 65 -> 56
+    // 128->128 @160 145 -> 107, 256->256 @80 114 -> 88, 128->128 @80 50 -> 35, 256->256 @40 40 -> 35, 256->512 @40 65 -> 56;
+    // with 16-byte stores (round 3): 91 / 99 / 86 / 32 / 36 / 56 us
     return g.Cd <= 32 ? 16 : 8;
 }
 
