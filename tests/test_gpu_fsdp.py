@@ -115,7 +115,10 @@ def test_sharded_wrappers_predictions_and_all_gradients(pg, wrapper, preset, pre
     # implementations of the contract are not correlated there, and the statistics' float atomics make the device's version
     # differ from run to run: one run in ~15 had 1.73 against 2 x 0.83 + 0.05 on a BatchNorm bias.  Such tensors are held to
     # the factor-2 rule or a norm bound (rel-L2 <= 2), whichever is wider; the median rule below holds the population.
-    bad = [(k, hip[k], cpu[k]) for k in hip if hip[k][1] > (2 * cpu[k][1] + 0.05 if cpu[k][1] <= 0.5 else max(2 * cpu[k][1] + 0.05, 2.0))]
+    band = {k: (2 * cpu[k][1] + 0.05 if cpu[k][1] <= 0.5 else max(2 * cpu[k][1] + 0.05, 2.0)) for k in hip}
+    worst = max(hip, key=lambda k: hip[k][1] / band[k])
+    print(f"  closest to its band: {worst} at {hip[worst][1]:.3f} of {band[worst]:.3f} (CPU {cpu[worst][1]:.3f})")
+    bad = [(k, hip[k], cpu[k]) for k in hip if hip[k][1] > band[k]]
     assert not bad, f"{len(bad)} tensors further from fp32 than twice the CPU path under the same contract: {bad[:5]}"
     assert med <= 1.25 * med16 + 0.01, (med, med16)
     # BatchNorm buffers follow the parameter dtype (reference :150-153) and hold the same running statistics

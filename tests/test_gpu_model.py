@@ -233,7 +233,12 @@ def test_all_gradients_within_band_of_fp32_oracle(preset, res, precision):
     print(msg + f" | CPU bf16 autocast: preds {_rel(p16, p_ref):.2e}, min cosine {min(c for c, _ in cpu.values()):.5f}, "
           f"median rel-L2 {med16:.4f}, max rel-L2 {max(r for _, r in cpu.values()):.4f}")
     assert e_p < 2 * _rel(p16, p_ref) + 1e-2
-    bad = [(k, hip[k], cpu[k]) for k in hip if hip[k][1] > 2 * cpu[k][1] + 0.05]
+    # (a tensor that is rounding noise on the CPU under the same numeric contract too -- CPU rel-L2 > 0.5 -- is held to the wider
+    # of the factor-2 band and a norm bound of 2: tests/test_gpu_fsdp.py explains)
+    band = {k: (2 * cpu[k][1] + 0.05 if cpu[k][1] <= 0.5 else max(2 * cpu[k][1] + 0.05, 2.0)) for k in hip}
+    worst = max(hip, key=lambda k: hip[k][1] / band[k])
+    print(f"  closest to its band: {worst} at {hip[worst][1]:.3f} of {band[worst]:.3f} (CPU {cpu[worst][1]:.3f})")
+    bad = [(k, hip[k], cpu[k]) for k in hip if hip[k][1] > band[k]]
     assert not bad, f"{len(bad)} tensors further from fp32 than twice the CPU bf16 path: {bad[:5]}"
     assert med <= 1.25 * med16 + 0.01, (med, med16)
 
