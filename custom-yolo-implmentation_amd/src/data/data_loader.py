@@ -27,6 +27,57 @@ class DevicePreppedLoader:
             yield self.transform(images, targets)
 
 
+class DevicePrefetcher:
+    """One batch of lookahead on a second HIP stream: while the training step of batch i runs, batch i+1 is produced on the
+    side stream -- whatever device work the wrapped loader does to produce it (DevicePreppedLoader: the pinned upload and the
+    transform kernels) plus the host -> device copy of a CPU image tensor (pinned by the DataLoader: asynchronous).  Copies
+    and compute then overlap instead of queueing on one stream (a 32 x 3 x 640 x 640 fp32 batch is 157 MB: 3 - 6 ms of PCIe
+    time against a 10.4 ms step).  The consumer's stream waits on the batch's event before it sees the tensor; the tensor is
+    recorded on that stream so that the allocator does not hand its memory to the next upload while the step still reads it.
+    Yields what the loader yields, with the images on the device."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):                # sampler / dataset / batch_size of the wrapped loader
+        return getattr(self.loader, name)
+
+    def _produce(self, it):
+        with torch.cuda.stream(self.stream):
+            try:
+                images, targets = next(it)
+            except StopIteration:
+                return None
+            if isinstance(images, torch.Tensor) and not images.is_cuda:
+                images = images.to(self.device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return images, targets, ready
+
+    def __iter__(self):
+        if self.device.type != "cuda":
+            yield from self.loader
+            return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(self.device)
+        it = iter(self.loader)
+        cur = self._produce(it)
+        while cur is not None:
+            images, targets, ready = cur
+            consumer = torch.cuda.current_stream(self.device)
+            consumer.wait_event(ready)
+            if isinstance(images, torch.Tensor):
+                images.record_stream(consumer)
+            yield images, targets
+            # the consumer has issued its step for this batch (asynchronously) and asks for the next one: produce it now, beside
+            # that step
+            cur = self._produce(it)
+
+
 class SyntheticDetectionDataset(Dataset):
     """randn images; 1..20 boxes (cx,cy,w,h,cls) in pixels per image."""
 

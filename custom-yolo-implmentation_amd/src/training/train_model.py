@@ -185,6 +185,9 @@ class ShardedTraining(CapturedTraining):
 def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimizer=None, scaler=None, metrics=None,
                conf_threshold=0.25, num_classes=171, on_step=None, captured=None):
     sums = [0.0, 0.0, 0.0]
+    if device != "cpu" and torch.cuda.is_available():
+        from src.data.data_loader import DevicePrefetcher
+        loader = DevicePrefetcher(loader, device)            # the next batch's upload / transform beside this batch's step
     bar = tqdm(loader, desc=desc, disable=(rank != 0))
     for i, (images, targets) in enumerate(bar):
         images = images.to(device)

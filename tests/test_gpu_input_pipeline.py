@@ -81,3 +81,28 @@ def test_sampled_decisions_bf16_output_and_throughput():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
     print(f"\n[input pipeline] 32 images 480x640 -> 640x640 bf16 incl. pinned upload: {ms:.2f} ms / batch = {32e3 / ms:.0f} img/s")
+
+
+def test_device_prefetcher_yields_the_loader_s_batches_in_order_while_the_consumer_stream_is_busy():
+    """DevicePrefetcher (src/data/data_loader.py): batch i+1 is uploaded on a side stream while the consumer's stream still
+    works on batch i; the consumer sees every batch complete, in order, equal to the loader's own tensors -- also when it keeps
+    its stream busy, drops references early and the allocator recycles upload buffers."""
+    import torch
+    from src.data.data_loader import DevicePrefetcher
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(8, 3, 160, 160, generator=g).pin_memory(), [{"boxes": torch.full((2, 5), float(i))} for _ in range(8)])
+               for i in range(7)]
+    busy_a, busy_b = torch.randn(16 << 20, device="cuda"), torch.empty(16 << 20, device="cuda")
+    seen = 0
+    pf = DevicePrefetcher(batches, "cuda")
+    assert len(pf) == 7
+    for i, (img, tg) in enumerate(pf):
+        assert img.is_cuda and float(tg[0]["boxes"][0, 0]) == float(i)
+        for _ in range(3):
+            busy_b.copy_(busy_a)                       # the "step": the consumer stream has work queued when the next upload starts
+        s = (img.double() - batches[i][0].cuda().double()).abs().max()
+        assert float(s) == 0.0, (i, float(s))
+        del img
+        seen += 1
+    assert seen == 7
+    assert list(DevicePrefetcher(batches[:2], "cpu"))[1][0] is batches[1][0]      # CPU: the loader's own items, untouched
