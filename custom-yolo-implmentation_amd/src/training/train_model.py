@@ -185,30 +185,36 @@ class ShardedTraining(CapturedTraining):
 def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimizer=None, scaler=None, metrics=None,
                conf_threshold=0.25, num_classes=171, on_step=None, captured=None):
     sums = [0.0, 0.0, 0.0]
-    dev_sums = None
+    dev_sums = [None]
     if device != "cpu" and torch.cuda.is_available():
         from src.data.data_loader import DevicePrefetcher
         loader = DevicePrefetcher(loader, device)            # the next batch's upload / transform beside this batch's step
     bar = tqdm(loader, desc=desc, disable=(rank != 0))
+
+    def account(i, loss_dict):
+        scalars = getattr(loss_dict, "_scalars", None)
+        if scalars is not None and scalars.is_cuda:
+            # The step's three scalars stay on the device: reading them here would make the host wait for every step (the
+            # reference's three .item() calls do), and the next batch's upload could no longer run beside this step.  They
+            # are summed on the device in double; the progress bar catches up every tenth step.
+            dev_sums[0] = scalars.double() if dev_sums[0] is None else dev_sums[0] + scalars.double()
+            if rank == 0 and i % 10 == 9:
+                cur = dev_sums[0].tolist()
+                bar.set_postfix({"Loss": f"{(sums[0] + cur[0]) / (i + 1):.4f}", "Box": f"{(sums[1] + cur[1]) / (i + 1):.4f}",
+                                 "Cls": f"{(sums[2] + cur[2]) / (i + 1):.4f}"})
+        else:
+            for k, key in enumerate(("total_loss", "box_loss", "cls_loss")):
+                sums[k] += loss_dict[key]
+            bar.set_postfix({"Loss": f"{sums[0] / (i + 1):.4f}", "Box": f"{sums[1] / (i + 1):.4f}",
+                             "Cls": f"{sums[2] / (i + 1):.4f}"})
+        if on_step is not None:
+            on_step(i, loss_dict)
+
     for i, (images, targets) in enumerate(bar):
         images = images.to(device)
         loss_dict = captured.step(images, [t["boxes"] for t in targets]) if captured is not None else None
         if loss_dict is not None:
-            scalars = getattr(loss_dict, "_scalars", None)
-            if scalars is not None:
-                # The step's three scalars stay on the device: reading them here would make the host wait for every step (the
-                # reference's three .item() calls do), and the next batch's upload could no longer run beside this step.  They
-                # are summed on the device in double; the progress bar catches up every tenth step.
-                dev_sums = scalars.double() if dev_sums is None else dev_sums + scalars.double()
-                if rank == 0 and i % 10 == 9:
-                    cur = dev_sums.tolist()
-                    bar.set_postfix({"Loss": f"{(sums[0] + cur[0]) / (i + 1):.4f}", "Box": f"{(sums[1] + cur[1]) / (i + 1):.4f}",
-                                     "Cls": f"{(sums[2] + cur[2]) / (i + 1):.4f}"})
-            else:
-                for k, key in enumerate(("total_loss", "box_loss", "cls_loss")):
-                    sums[k] += loss_dict[key]
-            if on_step is not None:
-                on_step(i, loss_dict)
+            account(i, loss_dict)
             continue
         gt_box = [t["boxes"].to(device) for t in targets]
         if optimizer is not None:
@@ -228,14 +234,9 @@ def _run_epoch(model, loader, criterion, device, autocast_kw, rank, desc, optimi
             # one select + one matching launch per batch; images without ground truth are skipped (reference :326-328)
             rows, count = decode_predictions_packed(preds, anchors, strides, conf_threshold=conf_threshold)
             metrics.update_batch(rows, count, gt_box, skip_empty_targets=True)
-        for k, key in enumerate(("total_loss", "box_loss", "cls_loss")):
-            sums[k] += loss_dict[key]
-        bar.set_postfix({"Loss": f"{sums[0] / (i + 1):.4f}", "Box": f"{sums[1] / (i + 1):.4f}",
-                         "Cls": f"{sums[2] / (i + 1):.4f}"})
-        if on_step is not None:
-            on_step(i, loss_dict)
-    if dev_sums is not None:
-        sums = [a + b for a, b in zip(sums, dev_sums.tolist())]
+        account(i, loss_dict)
+    if dev_sums[0] is not None:
+        sums = [a + b for a, b in zip(sums, dev_sums[0].tolist())]
     n = max(len(loader), 1)
     return [s / n for s in sums]
 
