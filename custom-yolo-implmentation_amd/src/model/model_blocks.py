@@ -80,10 +80,31 @@ class C3K(nn.Module):
         self.conv3 = Conv(2 * half, out_ch, nn.SiLU())
         self.res_m = nn.Sequential(Residual(half, e=1.0), Residual(half, e=1.0))
 
+    def _fused_pair(self):
+        """After Model.fuse(): the two entry 1x1 convs read the same x, so they are ONE conv with the weights stacked along the
+        output channels (frozen: stacked once, kept until a weight is written to or moved) -- one launch and one read of x
+        instead of two."""
+        c1, c2 = self.conv1.conv, self.conv2.conv
+        key = (c1.weight.data_ptr(), c2.weight.data_ptr(), c1.weight._version, c2.weight._version, c1.bias._version, c2.bias._version)
+        hit = self.__dict__.get("_pair")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = torch.cat([c1.weight, c2.weight], 0).contiguous()
+                b = torch.cat([c1.bias, c2.bias], 0).contiguous()
+            hit = self.__dict__["_pair"] = (key, w, b)
+        return hit[1], hit[2]
+
     def forward(self, x, out=None, chunk_link=None):
         # both branches write their half of the concat buffer directly (no torch.cat copy)
         half = self.conv1.conv.out_channels
         buf = F_.cat_buffer(x, self.conv1.conv.weight, 2 * half)
+        if not hasattr(self.conv1, "norm") and not hasattr(self.conv2, "norm") and not torch.is_grad_enabled() and x.is_cuda:
+            # fused inference: the stacked conv fills the whole buffer; the first half is the residual chain's input and is
+            # overwritten by that chain's last block once its first block has consumed it (stream order)
+            w, b = self._fused_pair()
+            ab = F_.fused_conv_act(x, w, b, 1, 1, False, self.conv1._act, None, buf)
+            a = self.res_m[1](self.res_m[0](ab[:, :half]), out=buf[:, :half])
+            return self.conv3(F_.CatInto.apply(buf, a, ab[:, half:]), out=out)
         xa, link = F_.fan2(x)                                 # two 1x1 convs read x: the second data gradient is added to the first
         if link is not None:
             link.chunk = chunk_link

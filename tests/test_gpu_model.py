@@ -295,6 +295,9 @@ def test_fused_inference_equals_unfused_eval(precision):
             p2 = fused(img.cuda())[0]                      # second call: the cached packed weights
     finally:
         hops.stem_conv_fwd = real_stem
+    from src.model.model_blocks import C3K
+    c3k = [m for m in fused.modules() if type(m) is C3K]
+    assert c3k and all(m.__dict__.get("_pair") is not None for m in c3k), "C3K's two entry convs must run as one stacked conv"
     assert stem_calls[-2:] == [True, True], "the fused model's stem must take the stem kernel with bias + SiLU in its epilogue"
     ps = ParamStore(7)
     with torch.no_grad():
