@@ -224,13 +224,19 @@ def measure_fsdp2(preset, batch, res, nc, dev, steps, warmup, precision="bfloat1
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # a HOST-bound figure (the device idles: tools/fsdp2_steps.py) on a box whose host cores are shared: three windows, the
+        # fastest one reported, all three listed
+        windows = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            torch.cuda.synchronize()
+            windows.append(time.perf_counter() - t0)
+        dt = min(windows)
         groups = sum(1 for m in model.modules() if type(m).__name__.startswith("FSDP"))
         return dict(images_per_s=round(batch * steps / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), steps=steps, batch=batch,
+                    windows_ms_per_step=[round(1e3 * w / steps, 2) for w in windows],
                     final_loss=round(float(loss), 5), wrapper="prepare_fsdp2_model", fsdp_groups=groups, world=1, eager=True,
                     optimizer=type(opt).__name__, param_dtype=precision)
     finally:
@@ -566,7 +572,7 @@ def main():
             extra["inference_l_1280_fp16_fused"] = measure_inference(dev)
             extra["inference_one_image_fp16_fused"] = {p: measure_single_image(dev, p) for p in ("s", "l")}
             extra["preset_s_640_bf16_32img_deterministic_mode"] = measure_preset("s", args.batch, args.res, nc, dev, steps=10, warmup=3, deterministic=True)
-            extra["preset_l_fsdp2_bf16_16img"] = measure_fsdp2("l", 16, args.res, nc, dev, steps=10, warmup=3)
+            extra["preset_l_fsdp2_bf16_16img"] = measure_fsdp2("l", 16, args.res, nc, dev, steps=8, warmup=3)
             extra["preset_l_sharded_captured_bf16_16img"] = measure_sharded("l", 16, args.res, nc, dev, steps=20, warmup=5)
         except Exception as e:                     # never lose the headline line to an extra
             extra["error"] = repr(e)
