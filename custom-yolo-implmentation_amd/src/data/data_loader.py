@@ -44,6 +44,8 @@ class DevicePrefetcher:
         return len(self.loader)
 
     def __getattr__(self, name):                # sampler / dataset / batch_size of the wrapped loader
+        if name in ("loader", "device", "stream"):      # (not set yet: copy / pickle probing an empty instance)
+            raise AttributeError(name)
         return getattr(self.loader, name)
 
     def _produce(self, it):
