@@ -175,3 +175,19 @@ def test_checkpoints_load_under_any_wrapper_prefix(tmp_path):
     assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), c.state_dict().values()))
     sa, sc = opt_a.state_dict()["state"], opt_c.state_dict()["state"]
     assert sa.keys() == sc.keys() and all(torch.equal(sa[k]["exp_avg"], sc[k]["exp_avg"]) for k in sa)
+
+
+def test_device_prefetcher_is_transparent_without_a_gpu():
+    """DevicePrefetcher on the CPU: the loader's own items, its length and its attributes (sampler / batch_size) -- the epoch
+    loops wrap every loader in it, so the CPU launch (BASELINE config 1) must see no difference."""
+    from src.data.data_loader import DevicePrefetcher
+
+    class L(list):
+        sampler, batch_size = "S", 2
+    items = L([(torch.zeros(2, 3, 4, 4), [{"boxes": torch.zeros(1, 5)}]), (torch.ones(2, 3, 4, 4), [{"boxes": torch.ones(2, 5)}])])
+    pf = DevicePrefetcher(items, "cpu")
+    got = list(pf)
+    assert len(pf) == 2 and got[0][0] is items[0][0] and got[1][1] is items[1][1]
+    assert pf.sampler == "S" and pf.batch_size == 2
+    with pytest.raises(AttributeError):
+        pf.no_such_attribute
